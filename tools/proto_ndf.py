@@ -1,0 +1,299 @@
+"""
+Algorithm prototype (numpy, dense linear algebra) for the GPU integrator:
+variable-order (1-5) quasi-constant-step NDF (Shampine & Reichelt, "The MATLAB
+ODE suite", 1997; Byrne & Hindmarsh 1975) with an analytic Jacobian.
+Development tool only -- not shipped, not imported by the package.
+"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, "/root/repo")
+kB = 8.61773e-5
+q_C = 1.602e-19
+eps0 = 8.854 * 1e-12 * 1e-9
+
+
+class Problem:
+    def __init__(self, state_user, units, ix, iniPar, thickness, nx):
+        s = np.asarray(state_user, float) * units
+        self.nx = nx
+        self.dx = thickness / nx
+        g = lambda n: s[ix[n]]
+        self.n0, self.p0, self.mun, self.mup = g("n0"), g("p0"), g("mu_n"), g("mu_p")
+        self.ks, self.Cn, self.Cp, self.Sf, self.Sb = g("ks"), g("Cn"), g("Cp"), g("Sf"), g("Sb")
+        self.tn, self.tp, self.Tm = g("tauN"), g("tauP"), g("Tm")
+        self.Lam = q_C / (g("eps") * eps0)
+        x = np.linspace(self.dx / 2, thickness - self.dx / 2, nx)
+        if len(iniPar) <= 3:
+            fl, al = iniPar[0] * 1e-14, iniPar[1] * 1e-7
+            dN = fl * al * np.exp(-al * x)
+            if len(iniPar) > 2 and int(iniPar[2]) < 0:
+                dN = dN[::-1]
+        else:
+            dN = np.asarray(iniPar) * 1e-21
+        N = dN + self.n0
+        P = dN + self.p0
+        E = np.concatenate([[0.0], self.Lam * self.dx * np.cumsum((P - self.p0) - (N - self.n0))])
+        self.y0 = np.concatenate([N, P, E])
+
+    def f(self, y):
+        L, dx = self.nx, self.dx
+        N, P, E = y[:L], y[L:2 * L], y[2 * L:]
+        NP = N * P - self.n0 * self.p0
+        Jn = np.zeros(L + 1)
+        Jp = np.zeros(L + 1)
+        Sft = self.Sf * NP[0] / (N[0] + P[0])
+        Sbt = self.Sb * NP[-1] / (N[-1] + P[-1])
+        Jn[0], Jn[L], Jp[0], Jp[L] = Sft, -Sbt, -Sft, Sbt
+        Dn, Dp = self.mun * kB * self.Tm, self.mup * kB * self.Tm
+        Jn[1:L] = self.mun * 0.5 * (N[:-1] + N[1:]) * E[1:L] + Dn * (N[1:] - N[:-1]) / dx
+        Jp[1:L] = self.mup * 0.5 * (P[:-1] + P[1:]) * E[1:L] - Dp * (P[1:] - P[:-1]) / dx
+        R = ((self.Cn * N + self.Cp * P) + self.ks + 1 / (self.tn * P + self.tp * N)) * NP
+        dN = (Jn[1:] - Jn[:-1]) / dx - R
+        dP = -(Jp[1:] - Jp[:-1]) / dx - R
+        dE = -(Jn + Jp) * self.Lam
+        return np.concatenate([dN, dP, dE])
+
+    def jac(self, y):
+        L, dx = self.nx, self.dx
+        S = 3 * L + 1
+        N, P, E = y[:L], y[L:2 * L], y[2 * L:]
+        J = np.zeros((S, S))
+        iN = lambda i: i
+        iP = lambda i: L + i
+        iE = lambda i: 2 * L + i
+        Dn, Dp = self.mun * kB * self.Tm, self.mup * kB * self.Tm
+        # edge fluxes i=1..L-1
+        dJn = {}
+        dJp = {}
+        for i in range(1, L):
+            dJn[i] = {iN(i - 1): 0.5 * self.mun * E[i] - Dn / dx, iN(i): 0.5 * self.mun * E[i] + Dn / dx,
+                      iE(i): self.mun * 0.5 * (N[i - 1] + N[i])}
+            dJp[i] = {iP(i - 1): 0.5 * self.mup * E[i] + Dp / dx, iP(i): 0.5 * self.mup * E[i] - Dp / dx,
+                      iE(i): self.mup * 0.5 * (P[i - 1] + P[i])}
+        NP0 = N[0] * P[0] - self.n0 * self.p0
+        s0 = N[0] + P[0]
+        dS0 = {iN(0): self.Sf * (P[0] * s0 - NP0) / s0 ** 2, iP(0): self.Sf * (N[0] * s0 - NP0) / s0 ** 2}
+        NPL = N[-1] * P[-1] - self.n0 * self.p0
+        sL = N[-1] + P[-1]
+        dSL = {iN(L - 1): self.Sb * (P[-1] * sL - NPL) / sL ** 2, iP(L - 1): self.Sb * (N[-1] * sL - NPL) / sL ** 2}
+        dJn[0] = dS0
+        dJp[0] = {k: -v for k, v in dS0.items()}
+        dJn[L] = {k: -v for k, v in dSL.items()}
+        dJp[L] = dSL
+        for i in range(L):
+            for k, v in dJn[i + 1].items():
+                J[iN(i), k] += v / dx
+            for k, v in dJn[i].items():
+                J[iN(i), k] -= v / dx
+            for k, v in dJp[i + 1].items():
+                J[iP(i), k] -= v / dx
+            for k, v in dJp[i].items():
+                J[iP(i), k] += v / dx
+            NP = N[i] * P[i] - self.n0 * self.p0
+            den = self.tn * P[i] + self.tp * N[i]
+            k_ = (self.Cn * N[i] + self.Cp * P[i]) + self.ks + 1 / den
+            dRdN = (self.Cn - self.tp / den ** 2) * NP + k_ * P[i]
+            dRdP = (self.Cp - self.tn / den ** 2) * NP + k_ * N[i]
+            for r in (iN(i), iP(i)):
+                J[r, iN(i)] -= dRdN
+                J[r, iP(i)] -= dRdP
+        for i in range(1, L):
+            for k, v in dJn[i].items():
+                J[iE(i), k] -= v * self.Lam
+            for k, v in dJp[i].items():
+                J[iE(i), k] -= v * self.Lam
+        return J
+
+    def signal(self, y):
+        L = self.nx
+        return self.dx * np.sum(self.ks * (y[:L] * y[L:2 * L] - self.n0 * self.p0)) * 1e23
+
+
+KAPPA = np.array([0, -0.1850, -1 / 9, -0.0823, -0.0415, 0])
+GAMMA = np.hstack((0, np.cumsum(1 / np.arange(1, 6))))
+ALPHA = (1 - KAPPA) * GAMMA
+ERRC = KAPPA * GAMMA + 1 / np.arange(1, 7)
+
+
+def change_D(D, order, factor):
+    I = np.arange(1, order + 1)[:, None]
+    Jm = np.arange(1, order + 1)
+
+    def compute_R(fac):
+        M = np.zeros((order + 1, order + 1))
+        M[1:, 1:] = (I - 1 - fac * Jm) / I
+        M[0] = 1
+        return np.cumprod(M, axis=0)
+    R = compute_R(factor)
+    U = compute_R(1)
+    RU = R.dot(U)
+    D[:order + 1] = np.dot(RU.T, D[:order + 1])
+
+
+def ndf(prob, t_out, rtol, atol, hmax=np.inf, h0=None, newton_tol_frac=None, max_order=5, verbose=False, banded=None):
+    y = prob.y0.copy()
+    S = y.size
+    t = 0.0
+    t_end = t_out[-1]
+    f0 = prob.f(y)
+    scale = atol + rtol * np.abs(y)
+    if h0 is None:
+        d0 = np.sqrt(np.mean((y / scale) ** 2))
+        d1 = np.sqrt(np.mean((f0 / scale) ** 2))
+        h0 = 0.01 * d0 / d1 if d0 > 1e-5 and d1 > 1e-5 else 1e-6
+        y1 = y + h0 * f0
+        f1 = prob.f(y1)
+        d2 = np.sqrt(np.mean(((f1 - f0) / scale) ** 2)) / h0
+        h1 = (0.01 / max(d1, d2)) ** 0.5 if max(d1, d2) > 1e-15 else max(1e-6, h0 * 1e-3)
+        h0 = min(100 * h0, h1)
+    h = min(h0, hmax)
+    D = np.zeros((8, S))
+    D[0] = y
+    D[1] = f0 * h
+    order = 1
+    n_equal = 0
+    newton_tol = max(10 * np.finfo(float).eps / rtol, min(0.03, rtol ** 0.5)) if newton_tol_frac is None else newton_tol_frac
+    J = prob.jac(y) if banded is None else y.copy()
+    LU = None
+    st = dict(nsteps=0, nfev=2, njev=1, nlu=0, nrej=0, nnewtfail=0, niter=0)
+    out = np.zeros(len(t_out))
+    out[0] = prob.signal(y)
+    io = 1
+    I = np.eye(S)
+    while io < len(t_out):
+        # one step
+        current_jac = False if st["nsteps"] else True
+        accepted = False
+        while not accepted:
+            t_new = t + h
+            y_pred = np.sum(D[:order + 1], axis=0)
+            scale = atol + rtol * np.abs(y_pred)
+            psi = np.dot(D[1:order + 1].T, GAMMA[1:order + 1]) / ALPHA[order]
+            c = h / ALPHA[order]
+            converged = False
+            while not converged:
+                if LU is None:
+                    LU = np.linalg.inv(I - c * J) if banded is None else banded[0](prob, J, c, 2 * ((prob.nx + 127) // 128) * 64)
+                    st["nlu"] += 1
+                d = np.zeros(S)
+                yk = y_pred.copy()
+                dn_old = None
+                rate = None
+                for k in range(4):
+                    fk = prob.f(yk)
+                    st["nfev"] += 1
+                    st["niter"] += 1
+                    if not np.all(np.isfinite(fk)):
+                        break
+                    dy = LU.dot(c * fk - psi - d) if banded is None else banded[1](LU, c * fk - psi - d)
+                    dn = np.sqrt(np.mean((dy / scale) ** 2))
+                    if dn_old is not None:
+                        rate = dn / dn_old
+                    if rate is not None and (rate >= 1 or rate ** (4 - k) / (1 - rate) * dn > newton_tol):
+                        break
+                    yk += dy
+                    d += dy
+                    if dn == 0 or (rate is not None and rate / (1 - rate) * dn < newton_tol):
+                        converged = True
+                        break
+                    dn_old = dn
+                if not converged:
+                    if current_jac:
+                        break
+                    J = prob.jac(y_pred) if banded is None else y_pred.copy()
+                    st["njev"] += 1
+                    LU = None
+                    current_jac = True
+            if not converged:
+                st["nnewtfail"] += 1
+                h *= 0.5
+                change_D(D, order, 0.5)
+                n_equal = 0
+                LU = None
+                continue
+            n_iter = k + 1
+            safety = 0.9 * (2 * 4 + 1) / (2 * 4 + n_iter)
+            scale = atol + rtol * np.abs(yk)
+            err = ERRC[order] * d
+            en = np.sqrt(np.mean((err / scale) ** 2))
+            if en > 1:
+                st["nrej"] += 1
+                fac = max(0.2, safety * en ** (-1 / (order + 1)))
+                h *= fac
+                change_D(D, order, fac)
+                n_equal = 0
+                LU = None
+            else:
+                accepted = True
+        st["nsteps"] += 1
+        n_equal += 1
+        t_old = t
+        t = t_new
+        y = yk
+        D[order + 2] = d - D[order + 1]
+        D[order + 1] = d
+        for i in reversed(range(order + 1)):
+            D[i] += D[i + 1]
+        # dense output
+        while io < len(t_out) and t_out[io] <= t * (1 + 1e-15):
+            tq = t_out[io]
+            yq = D[0].copy()
+            p = 1.0
+            for j in range(1, order + 1):
+                p *= (tq - (t - (j - 1) * h)) / (h * j)
+                yq += D[j] * p
+            out[io] = prob.signal(yq)
+            io += 1
+        if n_equal < order + 1:
+            continue
+        if order > 1:
+            em = np.sqrt(np.mean((ERRC[order - 1] * D[order] / scale) ** 2))
+        else:
+            em = np.inf
+        if order < max_order:
+            ep = np.sqrt(np.mean((ERRC[order + 1] * D[order + 2] / scale) ** 2))
+        else:
+            ep = np.inf
+        ens = np.array([em, en, ep])
+        with np.errstate(divide="ignore"):
+            facs = ens ** (-1 / np.arange(order, order + 3))
+        dorder = int(np.argmax(facs)) - 1
+        fac = min(10.0, safety * np.max(facs))
+        if h * fac > hmax:
+            fac = hmax / h
+        # deadband: keep h (and the LU) unless the change is worthwhile
+        if dorder == 0 and 0.9 <= fac < 1.2:
+            n_equal = order + 1 - 1  # re-test next step
+            continue
+        order += dorder
+        h *= fac
+        change_D(D, order, fac)
+        n_equal = 0
+        LU = None
+    return out, st
+
+
+if __name__ == "__main__":
+    from oracle import oracle as O
+    from metrotrpl_amd import workloads as W
+    ix = W.indexes()
+    un = W.units()
+    t = W.default_times()
+    c2 = W.config2(16)
+    cases = [("cfg3_m%d" % m, W.initial_state(), W.STAUB_FLUENCES[m], W.STAUB_LENGTHS[m]) for m in (0, 5)]
+    cases += [("cfg2_%d" % k, c2["states"][k], c2["iniPar"][k], 2000.0) for k in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3)]
+    for name, st, ini, th in cases:
+        g = O.Grid(th, 128, t, 4.0)
+        ost = {}
+        ref = O.solve(ini, g, st, ix, units=un, ini_mode="fluence", RTOL=1e-10, ATOL=1e-14, stats=ost)
+        prob = Problem(st, un, ix, ini, th, 128)
+        for rtol, atol in ((1e-6, 1e-12), (1e-7, 1e-13), (1e-8, 1e-14)):
+            t0 = time.time()
+            sig, s = ndf(prob, t, rtol, atol * np.max(prob.y0[:256]) / 1e-6, hmax=4.0)
+            m = ref > 1e-10 * ref[0]
+            rel = np.abs(sig - ref) / np.abs(ref)
+            print(f"{name} rtol={rtol:g}: maxrel={rel[m].max():.2e} med={np.median(rel[m]):.2e} decades={np.log10(ref[0]/ref[m][-1]):.1f} "
+                  f"{s} ({time.time()-t0:.1f}s) lsoda_tight={ost['nsteps']}")
