@@ -1,0 +1,173 @@
+/*
+ * metrotrpl_amd.h -- C ABI of the MI355X forward-solver engine for MetroTRPL's
+ * likelihood hot path.
+ *
+ * The reference has no FFI: its boundary is the Python import
+ *   from forward_solver import solve            (trial_move_evaluation.py:4)
+ *   from laplace import make_I_tables, do_irf_convolution, post_conv_trim
+ *                                                (trial_move_evaluation.py:6, metropolis.py:28)
+ *   from sim_utils import Grid                   (trial_move_evaluation.py:7)
+ * metrotrpl_amd/{forward_solver,laplace,sim_utils}.py keep those names and
+ * bind the entry points below through ctypes.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no C++/torch types; the library never keeps a
+ *    caller pointer after a call returns;
+ *  - every function returns an int status (MTRPL_OK = 0); nothing throws
+ *    across the boundary; mtrpl_last_error() gives the message;
+ *  - "host" entry points take host pointers and do the H2D/D2H themselves;
+ *    "_dev" entry points take device pointers + a hipStream_t (as void*) and
+ *    are asynchronous on that stream (inputs resident in HBM);
+ *  - all arithmetic is IEEE fp64.
+ */
+#ifndef METROTRPL_AMD_H
+#define METROTRPL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes -> Python exceptions raised by the shim (forward_solver.py:104,
+ * :115,:117,:140 ValueError; :37,:203,:225 NotImplementedError) */
+#define MTRPL_OK 0
+#define MTRPL_ERR_BAD_ARG 1     /* ValueError */
+#define MTRPL_ERR_UNSUPPORTED 2 /* NotImplementedError */
+#define MTRPL_ERR_DEVICE 3      /* RuntimeError: HIP failure */
+#define MTRPL_ERR_NO_DEVICE 4   /* RuntimeError: no gfx950 device / wrong arch */
+
+/* per-solve status written by the solve kernels */
+#define MTRPL_SOLVE_OK 0
+#define MTRPL_SOLVE_STOPPED_EARLY 1 /* integrator gave up: later samples computed
+                                       from a zeroed state, like forward_solver.py:168 */
+
+enum { MTRPL_MEAS_TRPL = 0, MTRPL_MEAS_TRTS = 1 };    /* forward_solver.py:186-203 */
+enum { MTRPL_MODEL_STD = 0, MTRPL_MODEL_TRAPS = 1 };  /* forward_solver.py:420-423 */
+enum { MTRPL_INI_DENSITY = 0, MTRPL_INI_FLUENCE = 1 }; /* forward_solver.py:100-117 */
+
+/* parameter slots of mtrpl_solve_desc.par, SOLVER units (= state * units,
+ * forward_solver.py:119,128-138) */
+enum {
+    MTRPL_P_N0 = 0, MTRPL_P_P0, MTRPL_P_MU_N, MTRPL_P_MU_P, MTRPL_P_KS, MTRPL_P_CN, MTRPL_P_CP,
+    MTRPL_P_SF, MTRPL_P_SB, MTRPL_P_TAUN, MTRPL_P_TAUP, MTRPL_P_EPS, MTRPL_P_TM,
+    MTRPL_P_KC, MTRPL_P_NT, MTRPL_P_TAUE, MTRPL_NPAR
+};
+
+/* One forward simulation = one call of forward_solver.solve (forward_solver.py:41-203)
+ * together with its Grid (sim_utils.py:246-277). */
+typedef struct mtrpl_solve_desc {
+    double par[16];   /* MTRPL_P_* slots */
+    double thickness; /* Grid.thickness [nm] */
+    double hmax;      /* Grid.hmax: max integrator step [ns] */
+    double rtol;      /* RTOL / ATOL of the call (defaults 1e-7 / 1e-10, :18-19) */
+    double atol;
+    double min_y;     /* Grid.min_y clamp (:190-192), output units */
+    double ini[3];    /* fluence mode: [fluence cm^-2, alpha cm^-1, direction] (:106-113) */
+    int32_t nx;       /* Grid.nx */
+    int32_t nt;       /* len(Grid.tSteps) */
+    int32_t meas;     /* MTRPL_MEAS_* */
+    int32_t model;    /* MTRPL_MODEL_* */
+    int32_t ini_mode; /* MTRPL_INI_* */
+    int32_t reserved;
+    int64_t ini_off;  /* density mode: first of nx values [cm^-3] in the ini array */
+    int64_t t_off;    /* first of nt values in the tsteps array (tsteps[t_off] must be 0) */
+    int64_t out_off;  /* first of nt values in the out array */
+} mtrpl_solve_desc;
+
+typedef struct mtrpl_ctx mtrpl_ctx;
+
+/* ---- context ---------------------------------------------------------- */
+int mtrpl_ctx_create(int device, mtrpl_ctx **ctx);
+int mtrpl_ctx_destroy(mtrpl_ctx *ctx);
+const char *mtrpl_last_error(const mtrpl_ctx *ctx);
+const char *mtrpl_version(void);
+/* tunables: "rtol_scale","rtol_cap","atol_rel","max_steps"  */
+int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value);
+int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value);
+
+/* ---- a1/a6/a7/a8/a9: batched forward solve ----------------------------- */
+/* replaces forward_solver.solve (forward_solver.py:41-203) for B calls at once.
+ * stats (may be NULL): 8 int32 per solve = steps, rhs evals, factorisations,
+ * jacobian refreshes, rejected steps, newton failures, final order, spare. */
+int mtrpl_solve_batch(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *descs,
+                      const double *ini, int64_t n_ini, const double *tsteps, int64_t n_t,
+                      double *out, int64_t n_out, int32_t *status, int32_t *stats);
+int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_descs,
+                          const double *d_ini, const double *d_tsteps, double *d_out,
+                          int32_t *d_status, int32_t *d_stats, void *stream);
+
+/* ---- a4/a5: RHS of the ODE system (forward_solver.py:332-418) ---------- */
+/* y, dy: [B, S] with S = 3nx+1 (std: N,P,E) or 4nx+1 (traps: N,Ntrap,P,E);
+ * par: [B,16] MTRPL_P_* slots; dx: [B]. Host pointers. */
+int mtrpl_rhs_batch(mtrpl_ctx *ctx, int64_t B, int32_t nx, int32_t model, const double *par,
+                    const double *dx, const double *y, double *dy);
+
+/* ---- a3: E_field (forward_solver.py:26-38), rows x nx -> rows x (nx+1) - */
+int mtrpl_E_field(mtrpl_ctx *ctx, int64_t rows, int32_t nx, const double *N, const double *P,
+                  double n0, double p0, double eps, double dx, double corner_E, double *E);
+
+/* ---- a7/a8: spatial integrals (forward_solver.py:228-274) -------------- */
+int mtrpl_calculate_PL(mtrpl_ctx *ctx, int64_t rows, int32_t nx, double dx, const double *N,
+                       const double *P, double ks, double n0, double p0, double *out);
+int mtrpl_calculate_TRTS(mtrpl_ctx *ctx, int64_t rows, int32_t nx, double dx, const double *N,
+                         const double *P, double mu_n, double mu_p, double n0, double p0,
+                         double *out);
+
+/* ---- test entry: one Newton linear solve (I - c*J(y)) x = b ------------- */
+/* y, b, x: [B, 3nx+1] std layout. Exposes the kernel's E-elimination +
+ * block cyclic-reduction solver for the parity tests. */
+int mtrpl_newton_probe(mtrpl_ctx *ctx, int64_t B, int32_t nx, const double *par, const double *dx,
+                       const double *c, const double *y, const double *b, double *x);
+
+/* ---- a10: IRF moment tables (laplace.py:13-41, :129-167) ---------------- */
+/* irf_t, irf_y: [nk]; table: [nk,3] (last row zero). */
+int mtrpl_make_I_table(mtrpl_ctx *ctx, int32_t nk, const double *irf_t, const double *irf_y,
+                       double *table);
+
+/* ---- a11/a12: IRF convolution (laplace.py:44-85, :170-212) -------------- */
+/* Number of convolved samples do_irf_convolution would return for a trace
+ * ending at t_end with IRF spacing dt_irf: len(arange(0,t_end+dt/4,dt/2)[::2]). */
+int64_t mtrpl_irf_conv_len(double t_end, double dt_irf);
+/* One trace (host pointers): t,y [nt] -> conv_t, conv_y [n_conv]; success flag
+ * as laplace.py:76-84. */
+int mtrpl_irf_convolve(mtrpl_ctx *ctx, int32_t nt, const double *t, const double *y, int32_t nk,
+                       const double *table, double dt_irf, int32_t time_max_shift, int64_t n_conv,
+                       double *conv_t, double *conv_y, int32_t *success);
+/* laplace.py:170-212 alone: resampled_y [n] -> h_k [(n-1)/2+1] */
+int mtrpl_convolve(mtrpl_ctx *ctx, int64_t n, const double *resampled_y, int32_t nk,
+                   const double *table, double *h_k);
+
+/* ---- a13: the 1-D linear interpolation of post_conv_trim (laplace.py:121) and of
+ * the resampling step (laplace.py:74): scipy griddata semantics, NaN outside. */
+int mtrpl_interp_linear(mtrpl_ctx *ctx, int64_t n, const double *x, const double *y, int64_t nq,
+                        const double *xq, double *yq);
+
+/* ---- a11-a14 fused, batched, device-resident: solve output -> log-likelihood
+ * (trial_move_evaluation.py:75-158, laplace.py:44-126). See DESIGN.md. ---- */
+typedef struct mtrpl_like_desc {
+    int64_t sig_off;   /* first of nt simulated samples (output of the solve) */
+    int64_t t_off;     /* simulation times (nt) */
+    int64_t exp_off;   /* first of n_exp experimental times/vals/uncs */
+    int32_t nt;
+    int32_t n_exp;
+    int32_t irf;       /* index of the IRF table to apply, -1 = none */
+    int32_t reserved;
+    double scale_shift; /* log10(scale factor), trial_move_evaluation.py:58 */
+    double sigma;       /* model_uncertainty[meas_type] */
+} mtrpl_like_desc;
+
+int mtrpl_irf_tables_upload(mtrpl_ctx *ctx, int32_t n_tables, const int32_t *nk,
+                            const double *tables /* concatenated [nk,3] */, const double *dt_irf);
+/* ll[B, nT]: -sum err_sq / (sigma^2 T + 2 u^2) per measurement and temperature;
+ * -inf where the reference would return -inf.  max_nt >= every desc's nt and
+ * n_exp (sizes the LDS staging; at most 1024 in this build). */
+int mtrpl_loglik_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_like_desc *d_descs,
+                           const double *d_sig, const double *d_tsteps, const double *d_exp_t,
+                           const double *d_exp_y, const double *d_exp_u, const double *d_T,
+                           int32_t nT, int32_t max_nt, double *d_ll, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,191 @@
+"""ctypes binding of the C ABI in include/metrotrpl_amd.h.
+
+There is no CPU fallback: if the HIP library is missing, or no gfx950 device is
+present, every compute entry point raises RuntimeError.
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "lib", "libmetrotrpl_amd.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NO_DEVICE = 0, 1, 2, 3, 4
+MEAS = {"TRPL": 0, "TRTS": 1}
+MODEL = {"std": 0, "traps": 1}
+INI = {"density": 0, "fluence": 1}
+PAR_SLOTS = ["n0", "p0", "mu_n", "mu_p", "ks", "Cn", "Cp", "Sf", "Sb", "tauN", "tauP", "eps", "Tm",
+             "kC", "Nt", "tauE"]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class SolveDesc(C.Structure):
+    """mtrpl_solve_desc"""
+    _fields_ = [("par", C.c_double * 16), ("thickness", C.c_double), ("hmax", C.c_double),
+                ("rtol", C.c_double), ("atol", C.c_double), ("min_y", C.c_double),
+                ("ini", C.c_double * 3), ("nx", C.c_int32), ("nt", C.c_int32), ("meas", C.c_int32),
+                ("model", C.c_int32), ("ini_mode", C.c_int32), ("reserved", C.c_int32),
+                ("ini_off", C.c_int64), ("t_off", C.c_int64), ("out_off", C.c_int64)]
+
+
+class LikeDesc(C.Structure):
+    """mtrpl_like_desc"""
+    _fields_ = [("sig_off", C.c_int64), ("t_off", C.c_int64), ("exp_off", C.c_int64),
+                ("nt", C.c_int32), ("n_exp", C.c_int32), ("irf", C.c_int32), ("reserved", C.c_int32),
+                ("scale_shift", C.c_double), ("sigma", C.c_double)]
+
+
+SOLVE_DESC_DTYPE = np.dtype([("par", "f8", 16), ("thickness", "f8"), ("hmax", "f8"), ("rtol", "f8"),
+                             ("atol", "f8"), ("min_y", "f8"), ("ini", "f8", 3), ("nx", "i4"),
+                             ("nt", "i4"), ("meas", "i4"), ("model", "i4"), ("ini_mode", "i4"),
+                             ("reserved", "i4"), ("ini_off", "i8"), ("t_off", "i8"), ("out_off", "i8")],
+                            align=True)
+LIKE_DESC_DTYPE = np.dtype([("sig_off", "i8"), ("t_off", "i8"), ("exp_off", "i8"), ("nt", "i4"),
+                            ("n_exp", "i4"), ("irf", "i4"), ("reserved", "i4"), ("scale_shift", "f8"),
+                            ("sigma", "f8")], align=True)
+assert SOLVE_DESC_DTYPE.itemsize == C.sizeof(SolveDesc)
+assert LIKE_DESC_DTYPE.itemsize == C.sizeof(LikeDesc)
+
+# every symbol include/metrotrpl_amd.h declares: (restype, argtypes)
+_vp = C.c_void_p
+SIGNATURES = {
+    "mtrpl_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "mtrpl_ctx_destroy": (C.c_int, [_vp]),
+    "mtrpl_last_error": (C.c_char_p, [_vp]),
+    "mtrpl_version": (C.c_char_p, []),
+    "mtrpl_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
+    "mtrpl_get_option": (C.c_int, [_vp, C.c_char_p, _dp]),
+    "mtrpl_solve_batch": (C.c_int, [_vp, C.c_int64, _vp, _dp, C.c_int64, _dp, C.c_int64, _dp, C.c_int64,
+                                    _ip, _ip]),
+    "mtrpl_solve_batch_dev": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mtrpl_rhs_batch": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp]),
+    "mtrpl_E_field": (C.c_int, [_vp, C.c_int64, C.c_int32, _dp, _dp, C.c_double, C.c_double, C.c_double,
+                                C.c_double, C.c_double, _dp]),
+    "mtrpl_calculate_PL": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_double, _dp, _dp, C.c_double,
+                                     C.c_double, C.c_double, _dp]),
+    "mtrpl_calculate_TRTS": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_double, _dp, _dp, C.c_double,
+                                       C.c_double, C.c_double, C.c_double, _dp]),
+    "mtrpl_newton_probe": (C.c_int, [_vp, C.c_int64, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "mtrpl_make_I_table": (C.c_int, [_vp, C.c_int32, _dp, _dp, _dp]),
+    "mtrpl_irf_conv_len": (C.c_int64, [C.c_double, C.c_double]),
+    "mtrpl_irf_convolve": (C.c_int, [_vp, C.c_int32, _dp, _dp, C.c_int32, _dp, C.c_double, C.c_int32,
+                                     C.c_int64, _dp, _dp, _ip]),
+    "mtrpl_convolve": (C.c_int, [_vp, C.c_int64, _dp, C.c_int32, _dp, _dp]),
+    "mtrpl_interp_linear": (C.c_int, [_vp, C.c_int64, _dp, _dp, C.c_int64, _dp, _dp]),
+    "mtrpl_irf_tables_upload": (C.c_int, [_vp, C.c_int32, _ip, _dp, _dp]),
+    "mtrpl_loglik_batch_dev": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32,
+                                         C.c_int32, _vp, _vp]),
+}
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    srcs.append(os.path.join(_REPO, "include", "metrotrpl_amd.h"))
+    if not force and os.path.exists(LIB_PATH) and all(
+            os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-o", LIB_PATH, os.path.join(CSRC, "mtrpl_capi.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load the shared library (raises RuntimeError if it was never built)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
+                                   "g.build()'` (needs hipcc). There is no CPU fallback.")
+            L = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(L, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = L
+    return _lib
+
+
+class Context:
+    """mtrpl_ctx: one per process and GPU; blocking calls; not thread-safe."""
+
+    def __init__(self, device=0):
+        self._h = _vp()
+        rc = lib().mtrpl_ctx_create(int(device), C.byref(self._h))
+        if rc != OK:
+            self._h = None
+            raise RuntimeError(f"mtrpl_ctx_create(device={device}) failed with code {rc}: "
+                               "no MI355X (gfx950) device visible. There is no CPU fallback.")
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mtrpl_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def check(self, rc):
+        if rc == OK:
+            return
+        msg = lib().mtrpl_last_error(self._h)
+        msg = msg.decode() if msg else ""
+        if rc == ERR_BAD_ARG:
+            raise ValueError(msg)
+        if rc == ERR_UNSUPPORTED:
+            raise NotImplementedError(msg)
+        raise RuntimeError(f"metrotrpl_amd error {rc}: {msg}")
+
+    def set_option(self, key, value):
+        self.check(lib().mtrpl_set_option(self._h, key.encode(), float(value)))
+
+    def get_option(self, key):
+        v = C.c_double()
+        self.check(lib().mtrpl_get_option(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

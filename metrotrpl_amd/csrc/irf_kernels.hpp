@@ -1,0 +1,366 @@
+// irf_kernels.hpp -- instrument-response convolution (laplace.py) and the
+// likelihood tail (trial_move_evaluation.py:96-158) on the device.
+#pragma once
+#include "solver_device.hpp"
+
+namespace mtrpl {
+
+constexpr int kMaxIrfTables = 8;
+struct IrfTableSet {
+    int32_t n;
+    int32_t nk[kMaxIrfTables];
+    int64_t off[kMaxIrfTables];  // offset (in doubles) of table [nk,3] in the table buffer
+    double dt[kMaxIrfTables];    // mean(diff(t_irf)), laplace.py:66
+};
+
+// numpy.linspace(a, b, num)[i]
+__device__ inline double linspace_at(double a, double b, int num, int i)
+{
+    const double step = (b - a) / (double)(num - 1);
+    return (i == num - 1) ? b : a + (double)i * step;
+}
+
+// laplace.py:129-167 (I_moment, u_spacing = 1000) with scipy.integrate.simpson's
+// composite rule for an even number of equally spaced samples (basic Simpson on
+// the first N-1 samples + the Cartwright correction on the last interval).
+// One thread per (lag m, order n); laplace.py:13-41 leaves the last row zero.
+__global__ void make_I_table_kernel(const double *__restrict__ t, const double *__restrict__ y, int nk,
+                                    double *__restrict__ table)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 3 * nk) return;
+    const int m = idx / 3, n = idx % 3;
+    if (m >= nk - 1) { table[idx] = 0.0; return; }
+    constexpr int NU = 1000;
+    const double dt = t[1] - t[0];
+    const double du = linspace_at(0.0, 1.0, NU, 1) - linspace_at(0.0, 1.0, NU, 0);
+    const double ya = y[m + 1], yb = y[m];
+    auto val = [&](int i) {
+        const double u = linspace_at(0.0, 1.0, NU, i);
+        const double yi = linspace_at(ya, yb, NU, i);
+        const double w = (n == 0) ? 1.0 : ((n == 1) ? (u - 0.5) : (u - 0.5) * (u - 0.5));
+        return w * yi;
+    };
+    double result = 0.0;
+    for (int i = 0; i < NU - 3; i += 2) result += val(i) + 4.0 * val(i + 1) + val(i + 2);
+    result *= du / 3.0;
+    const double h0 = du, h1 = du;
+    const double alpha = (2 * h1 * h1 + 3 * h0 * h1) / (6 * (h1 + h0));
+    const double beta = (h1 * h1 + 3.0 * h0 * h1) / (6 * h0);
+    const double eta = (h1 * h1 * h1) / (6 * h0 * (h0 + h1));
+    result += alpha * val(NU - 1) + beta * val(NU - 2) - eta * val(NU - 3);
+    table[idx] = dt * result;
+}
+
+// 1-D linear interpolation exactly as scipy.interpolate.griddata does it for 1-D
+// points (interp1d linear, NaN outside the data): laplace.py:74, :121.
+__device__ inline double interp_linear(const double *x, const double *y, int n, double v)
+{
+    if (!(v >= x[0] && v <= x[n - 1])) return __builtin_nan("");
+    int lo = 0, hi = n;  // np.searchsorted(x, v, side="left")
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (x[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    int idx = lo < 1 ? 1 : lo;
+    if (idx > n - 1) idx = n - 1;
+    const double slope = (y[idx] - y[idx - 1]) / (x[idx] - x[idx - 1]);
+    return slope * (v - x[idx - 1]) + y[idx - 1];
+}
+
+__global__ void interp_kernel(const double *__restrict__ x, const double *__restrict__ y, int n,
+                              const double *__restrict__ xq, int64_t nq, double *__restrict__ yq)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq) yq[i] = interp_linear(x, y, n, xq[i]);
+}
+
+// resampled_t[i] of laplace.py:68-72
+__device__ inline double resampled_time(int64_t i, int64_t n_r, double half_dt, double t_end)
+{
+    double tq = (double)i * half_dt;
+    if (i == n_r - 1 && tq > t_end) tq = t_end;
+    return tq;
+}
+
+// laplace.py:68-77: resample (t, y) onto the dt_irf/2 grid
+__global__ void resample_kernel(const double *__restrict__ t, const double *__restrict__ y, int nt, double half_dt,
+                                int64_t n_r, double *__restrict__ ry, int32_t *__restrict__ nan_flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_r) return;
+    const double v = interp_linear(t, y, nt, resampled_time(i, n_r, half_dt, t[nt - 1]));
+    ry[i] = v;
+    if (v != v) atomicOr(nan_flag, 1);
+}
+
+// laplace.py:170-212 (convolve): h[0] = 0,
+// h[k] = sum_{j=max(0,k-nk)}^{k-1} I0[j] T[k-1-j][0] + I1[j] T[k-1-j][1] + I2[j] T[k-1-j][2].
+// 256 outputs per block; the block's window of I0/I1/I2 and the table sit in LDS.
+constexpr int kConvBlock = 256;
+__global__ __launch_bounds__(kConvBlock) void convolve_kernel(const double *__restrict__ ry, int64_t n,
+                                                              const double *__restrict__ table, int nk,
+                                                              double *__restrict__ h)
+{
+    extern __shared__ double smem[];
+    double *T = smem;                     // [nk][3]
+    double *I0 = T + 3 * nk;              // [kConvBlock + nk]
+    double *I1 = I0 + (kConvBlock + nk);
+    double *I2 = I1 + (kConvBlock + nk);
+    const int64_t nkk = (n - 1) / 2;      // last output index
+    const int64_t k0 = (int64_t)blockIdx.x * kConvBlock;
+    for (int i = threadIdx.x; i < 3 * nk; i += kConvBlock) T[i] = table[i];
+    const int64_t jbase = k0 - nk;        // first j needed by output k0 (may be < 0)
+    for (int i = threadIdx.x; i < kConvBlock + nk; i += kConvBlock) {
+        const int64_t j = jbase + i;
+        double a = 0.0, b = 0.0, c = 0.0;
+        if (j >= 0 && j < nkk) {
+            const double y0 = ry[2 * j], y1 = ry[2 * j + 1], y2 = ry[2 * j + 2];
+            c = 2 * (y2 - 2 * y1 + y0);  // I2, laplace.py:198
+            b = (y2 - y0);               // I1, :199
+            a = y1;                      // I0, :200
+        }
+        I0[i] = a; I1[i] = b; I2[i] = c;
+    }
+    __syncthreads();
+    const int64_t k = k0 + threadIdx.x;
+    if (k > nkk) return;
+    double acc = 0.0;
+    const int64_t taps = (k < nk) ? k : nk;
+    // j ascending == lag descending (same order as the sequential CPU sum)
+    for (int64_t m = taps - 1; m >= 0; --m) {
+        const int li = (int)(k - 1 - m - jbase);
+        acc += (I0[li] * T[3 * m] + I1[li] * T[3 * m + 1] + I2[li] * T[3 * m + 2]);
+    }
+    h[k] = acc;
+}
+
+// np.argmax ordering: a NaN beats every number, larger beats smaller, ties and
+// NaN-vs-NaN go to the smaller index.  (v, i) with i >= n is "empty".
+__device__ inline bool argmax_better(double vb, int64_t ib, double va, int64_t ia, int64_t n)
+{
+    if (ib >= n) return false;
+    if (ia >= n) return true;
+    const bool an = va != va, bn = vb != vb;
+    if (an || bn) return (an && bn) ? (ib < ia) : bn;
+    return vb > va || (vb == va && ib < ia);
+}
+
+// block-wide argmax of per-thread candidates (256 threads); result in sv[0], si[0]
+__device__ inline void block_argmax(double &best, int64_t &bi, int64_t n, double *sv, int64_t *si)
+{
+    sv[threadIdx.x] = best;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s &&
+            argmax_better(sv[threadIdx.x + s], si[threadIdx.x + s], sv[threadIdx.x], si[threadIdx.x], n)) {
+            sv[threadIdx.x] = sv[threadIdx.x + s];
+            si[threadIdx.x] = si[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    best = sv[0];
+    bi = si[0];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void argmax_kernel(const double *__restrict__ h, int64_t n, int64_t *__restrict__ out)
+{
+    __shared__ double sv[256];
+    __shared__ int64_t si[256];
+    double best = 0.0;
+    int64_t bi = n;
+    for (int64_t i = threadIdx.x; i < n; i += 256)
+        if (argmax_better(h[i], i, best, bi, n)) { best = h[i]; bi = i; }
+    block_argmax(best, bi, n, sv, si);
+    if (threadIdx.x == 0) out[0] = bi;
+}
+
+// conv_t = resampled_t[::2] (- conv_t[argmax] when shifting), laplace.py:80-84
+__global__ void conv_time_kernel(int64_t n_conv, int64_t n_r, double half_dt, double t_end, const int64_t *kmax,
+                                 int shift, double *__restrict__ conv_t)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_conv) return;
+    const double base = shift ? resampled_time(2 * kmax[0], n_r, half_dt, t_end) : 0.0;
+    const double v = resampled_time(2 * k, n_r, half_dt, t_end);
+    conv_t[k] = shift ? v - base : v;
+}
+
+// ---------------------------------------------------------------------------
+// Fused likelihood tail, one 256-thread block per (chain, measurement):
+// laplace.py:44-126 + trial_move_evaluation.py:96-158.  The convolved trace is
+// never written to HBM: pass A finds argmax over all n_conv samples chunk by
+// chunk in LDS, pass B recomputes only the (at most 2 per experimental time)
+// samples that the re-interpolation onto the experimental times needs.
+constexpr int kLikeBlock = 256;
+
+__device__ inline double conv_sample(const double *sig_t, const double *sig_y, int nt, const double *T, int nk,
+                                     int64_t k, int64_t n_r, double half_dt, double t_end)
+{
+    // h[k] straight from the definition (laplace.py:204-210), resampling on the fly
+    if (k <= 0) return 0.0;
+    const int64_t lo = (k - nk > 0) ? k - nk : 0;
+    double acc = 0.0;
+    double y0 = interp_linear(sig_t, sig_y, nt, resampled_time(2 * lo, n_r, half_dt, t_end));
+    for (int64_t j = lo; j < k; ++j) {
+        const double y1 = interp_linear(sig_t, sig_y, nt, resampled_time(2 * j + 1, n_r, half_dt, t_end));
+        const double y2 = interp_linear(sig_t, sig_y, nt, resampled_time(2 * j + 2, n_r, half_dt, t_end));
+        const double *tt = T + 3 * (k - 1 - j);
+        acc += (y1 * tt[0] + (y2 - y0) * tt[1] + (2 * (y2 - 2 * y1 + y0)) * tt[2]);
+        y0 = y2;
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_desc *__restrict__ descs,
+                                                            const double *__restrict__ sig,
+                                                            const double *__restrict__ tsteps,
+                                                            const double *__restrict__ exp_t,
+                                                            const double *__restrict__ exp_y,
+                                                            const double *__restrict__ exp_u,
+                                                            const double *__restrict__ temps, int nT, int max_nt,
+                                                            const double *__restrict__ tables, IrfTableSet set,
+                                                            double neg_frac_tol, double *__restrict__ ll, int64_t B)
+{
+    extern __shared__ double smem[];
+    __shared__ double red_v[kLikeBlock];
+    __shared__ int64_t red_i[kLikeBlock];
+    __shared__ int s_cnt[2];
+    const int64_t sidx = blockIdx.x;
+    if (sidx >= B) return;
+    const mtrpl_like_desc ds = descs[sidx];
+    const int nt = ds.nt, n_exp = ds.n_exp, tid = threadIdx.x;
+    if (nt > max_nt || n_exp > max_nt || n_exp > nt || nt < 2 || n_exp < 1) {  // caller broke its promise
+        for (int j = tid; j < nT; j += kLikeBlock) ll[sidx * nT + j] = __builtin_nan("");
+        return;
+    }
+    double *st = smem;            // [nt] simulation times
+    double *sy = st + nt;         // [nt] simulated signal
+    double *sol = sy + nt;        // [n_exp] signal at the experimental times
+    double *wk = sol + n_exp;     // IRF work space: T[3nk], I0,I1,I2[kLikeBlock+nk]
+    for (int i = tid; i < nt; i += kLikeBlock) { st[i] = tsteps[ds.t_off + i]; sy[i] = sig[ds.sig_off + i]; }
+    __syncthreads();
+    const double *et = exp_t + ds.exp_off, *ey = exp_y + ds.exp_off, *eu = exp_u + ds.exp_off;
+    int n_c = n_exp;  // number of compared samples
+    bool failed = false;
+    if (ds.irf >= 0) {
+        const int nk = set.nk[ds.irf];
+        const double *Tg = tables + set.off[ds.irf];
+        const double half_dt = set.dt[ds.irf] / 2, t_end = st[nt - 1];
+        // len(np.arange(0, t_end + dt/4, dt/2)), laplace.py:68
+        const int64_t n_r = (int64_t)ceil((t_end + set.dt[ds.irf] / 4) / half_dt);
+        const int64_t nkk = (n_r - 1) / 2;  // last convolved index
+        double *T = wk, *I0 = T + 3 * nk, *I1 = I0 + (kLikeBlock + nk), *I2 = I1 + (kLikeBlock + nk);
+        for (int i = tid; i < 3 * nk; i += kLikeBlock) T[i] = Tg[i];
+        // ---- pass A: argmax of the convolved trace (laplace.py:82) ----
+        double best = 0.0;
+        int64_t bi = nkk + 1;
+        for (int64_t k0 = 0; k0 <= nkk; k0 += kLikeBlock) {
+            const int64_t jbase = k0 - nk;
+            __syncthreads();
+            for (int i = tid; i < kLikeBlock + nk; i += kLikeBlock) {
+                const int64_t j = jbase + i;
+                double a = 0.0, b = 0.0, c = 0.0;
+                if (j >= 0 && j < nkk) {
+                    const double y0 = interp_linear(st, sy, nt, resampled_time(2 * j, n_r, half_dt, t_end));
+                    const double y1 = interp_linear(st, sy, nt, resampled_time(2 * j + 1, n_r, half_dt, t_end));
+                    const double y2 = interp_linear(st, sy, nt, resampled_time(2 * j + 2, n_r, half_dt, t_end));
+                    c = 2 * (y2 - 2 * y1 + y0); b = (y2 - y0); a = y1;
+                }
+                I0[i] = a; I1[i] = b; I2[i] = c;
+            }
+            __syncthreads();
+            const int64_t k = k0 + tid;
+            if (k <= nkk) {
+                double acc = 0.0;
+                const int64_t taps = (k < nk) ? k : nk;
+                for (int64_t m = taps - 1; m >= 0; --m) {
+                    const int li = (int)(k - 1 - m - jbase);
+                    acc += (I0[li] * T[3 * m] + I1[li] * T[3 * m + 1] + I2[li] * T[3 * m + 2]);
+                }
+                if (argmax_better(acc, k, best, bi, nkk + 1)) { best = acc; bi = k; }
+            }
+        }
+        block_argmax(best, bi, nkk + 1, red_v, red_i);
+        const double t_shift = resampled_time(2 * bi, n_r, half_dt, t_end);
+        const double ct_first = -t_shift;  // conv_t[0] after the shift
+        const double ct_last = resampled_time(2 * nkk, n_r, half_dt, t_end) - t_shift;
+        if (ct_last == 0.0 || best != best) failed = true;  // laplace.py:83-84, :76-77
+        // ---- post_conv_trim (laplace.py:120-124): exp_t < max(conv_t) ----
+        int cnt = 0;
+        for (int i = tid; i < n_exp; i += kLikeBlock) cnt += (et[i] < ct_last) ? 1 : 0;
+        if (tid == 0) s_cnt[0] = 0;
+        __syncthreads();
+        atomicAdd(&s_cnt[0], cnt);
+        __syncthreads();
+        // exp_t is increasing: the cut keeps indices 0..last index with exp_t < ct_last
+        n_c = s_cnt[0];
+        if (n_c == 0) failed = true;  // np.where(...)[0][-1] raises IndexError in the reference
+        // ---- pass B: re-interpolate onto the experimental times (laplace.py:121) ----
+        for (int i = tid; i < n_c; i += kLikeBlock) {
+            const double te = et[i];
+            double v;
+            if (!(te >= ct_first && te <= ct_last)) {
+                v = __builtin_nan("");
+            } else {
+                // searchsorted(conv_t, te, "left") on conv_t[k] = r_t[2k] - t_shift
+                int64_t lo = 0, hi = nkk + 1;
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (resampled_time(2 * mid, n_r, half_dt, t_end) - t_shift < te) lo = mid + 1; else hi = mid;
+                }
+                int64_t idx = lo < 1 ? 1 : lo;
+                if (idx > nkk) idx = nkk;
+                const double x0 = resampled_time(2 * (idx - 1), n_r, half_dt, t_end) - t_shift;
+                const double x1 = resampled_time(2 * idx, n_r, half_dt, t_end) - t_shift;
+                const double h0 = conv_sample(st, sy, nt, T, nk, idx - 1, n_r, half_dt, t_end);
+                const double h1 = conv_sample(st, sy, nt, T, nk, idx, n_r, half_dt, t_end);
+                const double slope = (h1 - h0) / (x1 - x0);
+                v = slope * (te - x0) + h0;
+            }
+            sol[i] = v;
+        }
+    } else {
+        // trial_move_evaluation.py:98-101: sol = sol[-len(times_c):]
+        for (int i = tid; i < n_exp; i += kLikeBlock) sol[i] = sy[nt - n_exp + i];
+    }
+    __syncthreads();
+    // ---- trial_move_evaluation.py:117-130: negative-fraction check, flip ----
+    int neg = 0;
+    for (int i = tid; i < n_c; i += kLikeBlock) neg += (sol[i] < 0) ? 1 : 0;
+    if (tid == 0) s_cnt[1] = 0;
+    __syncthreads();
+    atomicAdd(&s_cnt[1], neg);
+    __syncthreads();
+    if (!((double)s_cnt[1] < neg_frac_tol * (double)n_c)) failed = true;
+    // ---- :147-156: err_sq and ll(T) ----
+    double e2[4], u2[4];  // n_exp <= 4*kLikeBlock checked by the host
+    int cntp = 0;
+    for (int i = tid; i < n_c; i += kLikeBlock) {
+        double s = sol[i];
+        if (s < 0) s *= -1;
+        const double e = (log10(s) + ds.scale_shift - ey[i]);
+        e2[cntp] = e * e;
+        u2[cntp] = 2 * (eu[i] * eu[i]);
+        cntp++;
+    }
+    const double sg2 = ds.sigma * ds.sigma;
+    for (int j = 0; j < nT; ++j) {
+        const double Tj = temps[j];
+        double part = 0.0;
+        for (int q = 0; q < cntp; ++q) part += e2[q] / (sg2 * Tj + u2[q]);
+        part = wave_sum(part);
+        __syncthreads();
+        if ((tid & 63) == 0) red_v[tid >> 6] = part;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = -(red_v[0] + red_v[1] + red_v[2] + red_v[3]);
+            if (failed || tot != tot) tot = -__builtin_inf();  // :70-72,:159-165
+            ll[sidx * nT + j] = tot;
+        }
+    }
+}
+
+}  // namespace mtrpl

@@ -1,0 +1,207 @@
+"""GPU parity tests for the forward solver: HIP path (through the C ABI) vs
+golden vectors captured from the reference and vs the CPU oracle.
+
+Accuracy gate (SURVEY.md 8d / DESIGN.md): max |sig_gpu - sig_ref| / |sig_ref|
+<= 1e-6 against the reference at tight tolerance (RTOL=1e-10, ATOL=1e-14), over
+the samples within 4 decades of the trace's first sample -- the range over
+which the tight reference is itself converged to ~1e-8 (below that LSODA's own
+atol floor dominates: measured 2e-5 at 8 decades between 1e-10/1e-14 and
+1e-12/1e-18 runs).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+REL_TOL = 1e-6
+DECADES = 1e-4
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(G, "solve.npz"))
+
+
+@pytest.fixture(scope="module")
+def conv():
+    """Oracle at RTOL=1e-12/ATOL=1e-17 (tests/golden/make_converged.py)."""
+    return np.load(os.path.join(G, "solve_converged.npz"))
+
+
+@pytest.fixture(scope="module")
+def rhsg():
+    return np.load(os.path.join(G, "rhs.npz"))
+
+
+def _case(gold, key):
+    names, meas, solver, model, ini_mode = [str(x) for x in gold[key + "__meta"]]
+    thickness, nx, hmax, rtol, atol, min_y = gold[key + "__geom"]
+    return dict(names=names.split(","), meas=meas, solver=solver, model=model, ini_mode=ini_mode,
+                thickness=float(thickness), nx=int(nx), hmax=float(hmax), rtol=float(rtol), atol=float(atol),
+                min_y=None if min_y < 0 else float(min_y), tSteps=gold[key + "__tSteps"],
+                state=gold[key + "__state"], units=gold[key + "__units"], iniPar=gold[key + "__iniPar"],
+                sig=gold[key + "__sig"])
+
+
+def _relerr(sig, ref, floor=DECADES):
+    m = np.abs(ref) >= floor * np.abs(ref[0])
+    return np.max(np.abs(sig[m] - ref[m]) / np.abs(ref[m])), int(m.sum())
+
+
+def test_rhs_matches_reference(rhsg):
+    """forward_solver.py:332-372 on random states (a4).  The kernel keeps the
+    reference's operation order; hipcc may contract a*b+c, so agreement is to
+    rounding of the individual flux terms, not bitwise."""
+    from metrotrpl_amd import batch
+    from metrotrpl_amd.forward_solver import q_C, eps0
+    n = 0
+    for k in range(int(rhsg["n_cases"])):
+        a = rhsg[f"std{k}_args"]
+        L = int(a[0])
+        if L > 128:
+            continue
+        par = np.array([[a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12],
+                         q_C / (a[13] * eps0), a[14], 0, 0, 1]])
+        y = rhsg[f"std{k}_y"]
+        dy = batch.rhs_batch(par, [a[1]], y[None, :], L)[0]
+        ref = rhsg[f"std{k}_dy"]
+        # dN, dP are differences of fluxes ~1e3x larger than the result: scale by the flux magnitude
+        scale = np.max(np.abs(ref[:2 * L])) + 1e-300
+        np.testing.assert_allclose(dy[:2 * L], ref[:2 * L], rtol=1e-9, atol=1e-12 * scale)
+        np.testing.assert_allclose(dy[2 * L:], ref[2 * L:], rtol=1e-12, atol=1e-14 * np.max(np.abs(ref[2 * L:])))
+        n += 1
+    assert n >= 4
+
+
+def test_newton_linear_solver():
+    """E-elimination + cyclic reduction == dense solve of (I - cJ) x = b."""
+    from metrotrpl_amd import batch, workloads as W
+    from tools.proto_ndf import Problem
+    ix, un = W.indexes(), W.units()
+    c2 = W.config2(6)
+    rng = np.random.default_rng(0)
+    for nx in (128, 100, 37):
+        for k in range(6):
+            th = 2000.0 if k % 2 else 311.0
+            prob = Problem(c2["states"][k], un, ix, c2["iniPar"][k], th, nx)
+            y = prob.y0.copy()
+            y[:2 * nx] *= 10 ** rng.uniform(-0.3, 0.3, 2 * nx)
+            y[2 * nx:] += rng.normal(0, 1e-5, nx + 1)
+            par = batch.pack_params((c2["states"][k] * un)[None, :], ix)
+            for c in (1e-6, 1e-2, 1.0):
+                M = np.eye(y.size) - c * prob.jac(y)
+                b = rng.normal(0, 1, y.size) * np.abs(y)
+                b[2 * nx] = 0.0
+                b[-1] = 0.0
+                x_ref = np.linalg.solve(M, b)
+                x = batch.newton_probe(par, [prob.dx], [c], y[None, :], b[None, :], nx)[0]
+                res = np.linalg.norm(M @ x - b) / np.linalg.norm(b)
+                assert res < 1e-6, (nx, k, c, res)
+                np.testing.assert_allclose(x, x_ref, rtol=1e-5, atol=1e-7 * np.max(np.abs(x_ref)))
+
+
+def _run(c, rtol=None, atol=None):
+    from metrotrpl_amd import batch
+    idx = {n: i for i, n in enumerate(c["names"])}
+    sig, status, stats = batch.solve_batch(c["state"][None, :], idx, c["units"], c["iniPar"][None, :], c["thickness"],
+                                           c["nx"], c["tSteps"], hmax=c["hmax"], meas=c["meas"], model=c["model"],
+                                           ini_mode=c["ini_mode"], RTOL=c["rtol"] if rtol is None else rtol,
+                                           ATOL=c["atol"] if atol is None else atol, min_y=c["min_y"],
+                                           return_stats=True)
+    return sig[0], int(status[0]), stats[0]
+
+
+def test_golden_solves_tight(gold, conv):
+    """Every std-model golden case with nx <= 128, called with the DEFAULT
+    tolerances (1e-7 / 1e-10), against (a) the converged trace and (b) the
+    reference's own tight-tolerance output wherever that output is itself
+    converged (it is not for cfg2_11: 2.2e-6 from the converged trace)."""
+    worst = 0.0
+    n = 0
+    for key in [str(k) for k in gold["order"]]:
+        if not key.endswith("__tight"):
+            continue
+        c = _case(gold, key)
+        if c["model"] != "std" or c["nx"] > 128 or c["min_y"] is not None:
+            continue
+        sig, status, stats = _run(c, rtol=1e-7, atol=1e-10)
+        assert status == 0, key
+        err, npts = _relerr(sig, c["sig"])
+        cv = conv[key.replace("__tight", "__conv")]
+        err_c, _ = _relerr(sig, cv)
+        ref_gap, _ = _relerr(c["sig"], cv)
+        print(f"{key}: vs tight ref={err:.2e} vs converged={err_c:.2e} (ref gap {ref_gap:.1e}) over {npts} pts; "
+              f"steps={stats[0]} rhs={stats[1]} fac={stats[2]} jac={stats[3]} rej={stats[4]} nfail={stats[5]}")
+        worst = max(worst, err_c)
+        assert err_c <= REL_TOL, (key, err_c)
+        if ref_gap <= 3e-7:
+            assert err <= REL_TOL, (key, err)
+        n += 1
+    assert n >= 30
+    print("worst rel err:", worst)
+
+
+def test_golden_solves_default_reference(gold):
+    """Against the reference at ITS default tolerances the floor is the reference's
+    own error (1.9e-6 vs converged)."""
+    for key in [str(k) for k in gold["order"]]:
+        if not key.endswith("__default") or not key.startswith("cfg"):
+            continue
+        c = _case(gold, key)
+        if c["nx"] > 128:
+            continue
+        sig, status, _ = _run(c)
+        err, _ = _relerr(sig, c["sig"])
+        assert err <= 2e-5, (key, err)
+
+
+def test_min_y_clamp(gold):
+    """forward_solver.py:190-192, pin Tests/test_metropolis.py:199-266."""
+    c = _case(gold, "tm_depl__tight")
+    sig, status, _ = _run(c)
+    ref = c["sig"]
+    assert status == 0
+    assert np.min(sig) >= c["min_y"]
+    np.testing.assert_array_equal(sig[-10:], c["min_y"])
+    first_ref = int(np.argmax(ref == c["min_y"]))
+    first = int(np.argmax(sig == c["min_y"]))
+    assert abs(first - first_ref) <= 1
+    k = min(first, first_ref)
+    np.testing.assert_allclose(sig[:k], ref[:k], rtol=REL_TOL)
+
+
+def test_batch_equals_single(gold):
+    """A batch of different solves gives exactly what one-by-one calls give."""
+    from metrotrpl_amd import batch, workloads as W
+    ix, un = W.indexes(), W.units()
+    c2 = W.config2(8)
+    t = np.linspace(0, 300, 151)
+    sig = batch.solve_batch(c2["states"], ix, un, c2["iniPar"], 2000.0, 128, t)
+    for k in range(8):
+        one = batch.solve_batch(c2["states"][k:k + 1], ix, un, c2["iniPar"][k:k + 1], 2000.0, 128, t)[0]
+        np.testing.assert_array_equal(one, sig[k])
+
+
+def test_oracle_cross_check_random_draws():
+    """Config-2 draws beyond the committed golden subset, against the oracle
+    (SciPy LSODA + C RHS) at tight tolerance, computed on this machine."""
+    from metrotrpl_amd import batch, workloads as W
+    from oracle import oracle as O
+    ix, un = W.indexes(), W.units()
+    c2 = W.config2(40)
+    sel = np.arange(16, 40)
+    t = np.linspace(0, 2000, 1001)
+    sig, status, stats = batch.solve_batch(c2["states"][sel], ix, un, c2["iniPar"][sel], 2000.0, 128, t,
+                                           return_stats=True)
+    assert np.all(status == 0)
+    g = O.Grid(2000.0, 128, t, 4.0)
+    worst = 0.0
+    for j, k in enumerate(sel):
+        ref = O.solve(c2["iniPar"][k], g, c2["states"][k], ix, units=un, ini_mode="fluence", RTOL=1e-10, ATOL=1e-14)
+        err, _ = _relerr(sig[j], ref)
+        worst = max(worst, err)
+        assert err <= REL_TOL, (k, err, stats[j])
+    print("worst:", worst, "mean steps:", stats[:, 0].mean())
