@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X forward-solver engine.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "Config 2"): a 1024-solve
+synthetic batch per GPU, nx=128, thickness 2000 nm, 1001 output times over
+2000 ns, hmax=4, std model, TRPL, fp64, reference default tolerances.  One
+"step" = one launch of the batched solve kernel over that batch with every input
+(descriptors, time grid) already resident in HBM.  Ranks draw different states
+(weak scaling, no data-path collective: solves are independent).
+
+`--workload pt` runs the parallel-tempering power-scan instead (configs[2]/[3]:
+chains x 6 measurements, IRF convolution + likelihood on the device, RCCL
+all-gather of the per-chain log-likelihood table each step; strong scaling).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_solve(nx, nt, model="std", irf_nk=0):
+    """A = nt_out * 8 * (2S + 1), S = 3nx+1 (std) / 4nx+1 (traps)."""
+    S = (3 if model == "std" else 4) * nx + 1
+    a = nt * 8 * (2 * S + 1)
+    if irf_nk:
+        a += 8 * (3 * irf_nk + 2)
+    return a
+
+
+def cpu_baseline(sample=12):
+    """Oracle (SciPy LSODA driving the gcc-built RHS through a Python trampoline --
+    the reference's own structure with Numba replaced by gcc) on a bounded sample
+    of the SAME workload, one core (the reference's unit of parallelism is one
+    process per chain, metropolis.py:300)."""
+    from metrotrpl_amd import workloads as W
+    from oracle import oracle as O
+    O.build()
+    c = W.config2(sample)
+    ix, un = W.indexes(), W.units()
+    g = O.Grid(c["thickness"], c["nx"], c["tSteps"], c["hmax"])
+    O.solve(c["iniPar"][0], g, c["states"][0], ix, units=un, ini_mode="fluence")  # warm-up (dlopen, caches)
+    t0 = time.perf_counter()
+    for k in range(sample):
+        O.solve(c["iniPar"][k], g, c["states"][k], ix, units=un, ini_mode="fluence")
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+            "sample": f"first {sample} solves of the config-2 batch, SciPy LSODA (rtol 1e-7, atol 1e-10, max_step 4) "
+                      f"+ gcc -O2 RHS via ctypes, {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="solves per GPU and step (config 2: 1024)")
+    ap.add_argument("--workload", default="batch", choices=["batch", "pt"])
+    ap.add_argument("--chains", type=int, default=512, help="--workload pt: total PT chains (strong scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and a.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from metrotrpl_amd import _lib as L, batch, workloads as W
+    if a.workload == "pt":
+        from metrotrpl_amd import pt_bench
+        line = pt_bench.run(a, rank, world, local, dev)
+        if rank == 0:
+            print(json.dumps(line))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ctx = L.Context(local)
+    B = a.batch
+    # rank r takes draws [r*B, (r+1)*B) of the seeded config-2 stream
+    c = W.config2(B * world)
+    sl = slice(rank * B, (rank + 1) * B)
+    t_host = np.ascontiguousarray(c["tSteps"])
+    nt = t_host.shape[0]
+    descs, ini = batch.build_batch(c["states"][sl], W.indexes(), W.units(), c["iniPar"][sl], c["thickness"], c["nx"],
+                                   nt, hmax=c["hmax"], meas=c["meas"], model=c["model"], ini_mode=c["ini_mode"])
+    d_descs = torch.from_numpy(descs.view(np.uint8).reshape(-1)).to(dev)
+    d_ini = torch.from_numpy(ini).to(dev)
+    d_t = torch.from_numpy(t_host).to(dev)
+    d_out = torch.zeros(B * nt, dtype=torch.float64, device=dev)
+    d_status = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_stats = torch.zeros(B * 8, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        ctx.check(L.lib().mtrpl_solve_batch_dev(ctx.handle, B, d_descs.data_ptr(), d_ini.data_ptr(), d_t.data_ptr(),
+                                                d_out.data_ptr(), d_status.data_ptr(), d_stats.data_ptr(),
+                                                stream.cuda_stream))
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        ev[k][0].record(stream)
+        step()
+        ev[k][1].record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+
+    status = d_status.cpu().numpy()
+    stats = d_stats.cpu().numpy().reshape(B, 8)
+    sig = d_out.cpu().numpy().reshape(B, nt)
+    ok = bool(np.all(status == 0) and np.all(np.isfinite(sig)))
+
+    if rank == 0:
+        A = algorithmic_bytes_per_solve(c["nx"], nt)
+        achieved = A * B / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(REPO, "profiles", "hbm_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("solve_kernel_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "trpl_forward_solves_per_sec", "value": world * B * a.steps / dt, "unit": "solves/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "config2: 1024-solve synthetic batch per GPU, nx=128, 2000 nm single-layer absorber, "
+                                   "1001 output times over 2000 ns, hmax=4, std model, TRPL, rtol 1e-7 / atol 1e-10",
+                       "solves_per_gpu_per_step": B, "nx": int(c["nx"]), "nt_out": int(nt), "parallelism": f"batch-shard x{world}",
+                       "all_solves_ok": ok, "mean_integrator_steps": float(stats[:, 0].mean()),
+                       "mean_rhs_evals": float(stats[:, 1].mean())},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "solve_kernel_r2",
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_solve": A,
+                         "note": "state-streaming model of SURVEY.md 8d; the solve state is register-resident by "
+                                 "design, so HBM is not the limiter (see DESIGN.md)"},
+        }
+        if not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

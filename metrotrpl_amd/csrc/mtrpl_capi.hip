@@ -257,7 +257,7 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
     if (B <= 0) return MTRPL_OK;
     if (!d_descs || !d_tsteps || !d_out || !d_status) return bad(ctx, MTRPL_ERR_BAD_ARG, "null device pointer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t s = (hipStream_t)stream;  // exactly the caller's stream (NULL = the default stream)
     hipLaunchKernelGGL(solve_kernel_r2, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out, d_status,
                        d_stats, B, ctx->tune);
     HIP_TRY(ctx, hipGetLastError());

@@ -1,0 +1,65 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/metrotrpl_amd.h
+declares; struct layouts match; without a GPU the product path fails loudly."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from metrotrpl_amd import _lib
+    _lib.build()
+    return _lib.lib()
+
+
+def _declared():
+    src = open(os.path.join(REPO, "include", "metrotrpl_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mtrpl_[a-zA-Z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from metrotrpl_amd import _lib
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes signature table out of sync with the header"
+
+
+def test_version_and_struct_layout(lib):
+    from metrotrpl_amd import _lib
+    assert b"gfx950" in lib.mtrpl_version()
+    assert C.sizeof(_lib.SolveDesc) == 16 * 8 + 5 * 8 + 3 * 8 + 6 * 4 + 3 * 8 == _lib.SOLVE_DESC_DTYPE.itemsize
+    assert _lib.SOLVE_DESC_DTYPE.fields["ini_off"][1] == C.sizeof(_lib.SolveDesc) - 24
+    assert C.sizeof(_lib.LikeDesc) == _lib.LIKE_DESC_DTYPE.itemsize == 56
+    assert lib.mtrpl_irf_conv_len(2000.0, 0.025) == 80001
+    assert lib.mtrpl_irf_conv_len(10.0, 0.01) == 1001
+
+
+def test_no_gpu_means_loud_failure(lib):
+    import torch
+    from metrotrpl_amd import _lib, batch, workloads as W
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.Context(0)
+    with pytest.raises(RuntimeError):
+        batch.solve_batch(W.initial_state()[None, :], W.indexes(), W.units(), [[1e12, 6e4, 1]], 311.0, 64,
+                          np.linspace(0, 10, 11))
+
+
+def test_product_never_imports_oracle():
+    """The shipped package must not reference oracle/ (or the reference) anywhere."""
+    pkg = os.path.join(REPO, "metrotrpl_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".inc", ".h", ".cpp")):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "mtrpl_oracle" not in txt, f
+                assert "/root/reference" not in txt, f

@@ -1,0 +1,113 @@
+"""CPU-only: pin the oracle's solve() / likelihood restatement against outputs of
+the reference itself (tests/golden/solve.npz, eval.npz) and the reference's own
+known-answer tests."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(G, "solve.npz"))
+
+
+def _solve_case(gold, key):
+    names, meas, solver, model, ini_mode = [str(x) for x in gold[key + "__meta"]]
+    th, nx, hmax, rtol, atol, min_y = gold[key + "__geom"]
+    g = O.Grid(float(th), int(nx), gold[key + "__tSteps"], float(hmax))
+    if min_y >= 0:
+        g.min_y = float(min_y)
+    idx = {n: i for i, n in enumerate(names.split(","))}
+    return O.solve(gold[key + "__iniPar"], g, gold[key + "__state"], idx, meas=meas, units=gold[key + "__units"],
+                   solver=(solver,), model=model, ini_mode=ini_mode, RTOL=float(rtol), ATOL=float(atol))
+
+
+@pytest.mark.parametrize("key", ["tm_rad__tight", "tm_rad_odeint__tight", "tm_trts__default", "tm_depl__tight",
+                                 "tm_flu__tight", "nx64__default", "nx64__tight", "cfg1_m0__default",
+                                 "cfg2_3__default", "trts_thin__default", "rev_thick__default",
+                                 "traps_thick__default"])
+def test_solve_reproduces_reference_bit_for_bit(gold, key):
+    """Same SciPy LSODA + same RHS arithmetic order => the reference's output to the last bit."""
+    sig = _solve_case(gold, key)
+    np.testing.assert_array_equal(sig, gold[key + "__sig"])
+
+
+def test_reference_known_answers(gold):
+    # Tests/test_metropolis.py:130-142: N0/(1+ks N0 t) -> 0.0009900990095719482 nm^-3 at t=100
+    sig = gold["tm_rad__tight__sig"]
+    ks, dx = 1e-11 * ((1e7) ** 3) / (1e9), 10.0
+    out_dN = np.full(100, 0.0009900990095719482)
+    rr = ks * out_dN * out_dN
+    expected = (np.sum((rr[1:] + rr[:-1]) / 2) * dx + rr[0] * dx / 2 + rr[-1] * dx / 2) * 1e23
+    assert abs(sig[-1] / sig[-1] - expected / sig[-1]) < 1e-7
+    # :186-187 the caller's state is intact afterwards
+    np.testing.assert_array_equal(gold["tm_trts__default__state_after"], gold["tm_trts__default__state"])
+    # :373-379 fluence mode == density mode
+    np.testing.assert_allclose(gold["tm_flu__tight__sig"][0] / gold["tm_flu__tight__sig"][0], 1.0)
+
+
+def test_oracle_errors():
+    from metrotrpl_amd import workloads as W
+    ix, un, s0 = W.indexes(), W.units(), W.initial_state()
+    g = O.Grid(311, 16, np.linspace(0, 1, 3), 4)
+    with pytest.raises(ValueError):
+        O.solve(np.ones(15), g, s0, ix, units=un)
+    with pytest.raises(ValueError):
+        O.solve([1, 2, 3, 4], g, s0, ix, units=un, ini_mode="fluence")
+    with pytest.raises(ValueError):
+        O.solve([1e12, 6e4], g, s0, ix, units=un, ini_mode="x")
+    with pytest.raises(ValueError):
+        O.solve([1e12, 6e4], g, s0, ix, units=un, ini_mode="fluence", model="x")
+    with pytest.raises(NotImplementedError):
+        O.solve([1e12, 6e4], g, s0, ix, units=un, ini_mode="fluence", meas="something else")
+    with pytest.raises(NotImplementedError):
+        O.solve([1e12, 6e4], g, s0, ix, units=un, ini_mode="fluence", solver=("somethign else",))
+
+
+def _eval_setup(ev, which):
+    names = [str(x) for x in ev[which + "__names"]]
+    idx = {n: names.index(n) for n in names}
+    t_end, nt = ev[which + "__t_end_nt"]
+    nt = int(nt)
+    times = [np.linspace(0, t_end, nt + 1), np.linspace(0, t_end, nt + 1)]
+    mtype = [str(x) for x in ev[which + "__mtype"]]
+    sig = ev[which + "__sigma"]
+    sigma = {"TRPL": sig[0]}
+    if sig[1] > 0:
+        sigma["TRTS"] = sig[1]
+    shared = {"units": ev[which + "__units"], "solver": ("solveivp",), "model": "std", "hmax": 4, "rtol": 1e-5,
+              "atol": 1e-8, "_sim_info": {"lengths": [2000, 2000], "nx": [128, 128], "meas_types": mtype,
+                                          "num_meas": 2},
+              "_param_indexes": idx, "_init_params": ev[which + "__ini"], "ini_mode": "density",
+              "_times": times, "_vals": list(ev[which + "__vals"]), "_uncs": list(ev[which + "__uncs"])}
+    if bool(ev[which + "__has_scale"]):
+        shared["scale_factor"] = (0.02, [0, 1, 2, 3, 4, 5], [(0, 2, 4), (1, 3, 5)])
+    if bool(ev[which + "__has_irf"]):
+        irf = np.load(os.path.join(G, "irf.npz"))
+        shared["irf_convolution"] = [745, 745]
+        shared["_IRF_tables"] = O.make_I_tables({745: irf["irf745_raw"]})
+    return ev[which + "__state"], {"model_uncertainty": sigma}, shared
+
+
+@pytest.mark.parametrize("which", ["base", "cutoff", "scale", "mixed", "irf"])
+def test_eval_trial_move_matches_reference(which):
+    """trial_move_evaluation.py:9-166 golden log-likelihoods (Tests/test_eval_trial_move.py
+    set-ups + one IRF case), at T=1, T=3 (ll_func) and T=7.5."""
+    ev = np.load(os.path.join(G, "eval.npz"))
+    state, uniq, shared = _eval_setup(ev, which)
+    logll, table = O.eval_trial_move(state, dict(uniq, _T=1.0), shared, temperatures=[1.0, 3.0, 7.5])
+    ref1, ref3, ref7 = float(ev[which + "__logll_T1"]), ev[which + "__ll_meas_T3"], float(ev[which + "__logll_T7p5"])
+    tol = dict(rtol=1e-9, atol=1e-25)
+    np.testing.assert_allclose(logll, ref1, **tol)
+    np.testing.assert_allclose(table[:, 0], ev[which + "__ll_meas_T1"], **tol)
+    np.testing.assert_allclose(table[:, 1], ref3, **tol)
+    np.testing.assert_allclose(np.sum(table[:, 2]), ref7, **tol)
+    # the reference's own coarse pins (Tests/test_eval_trial_move.py:79-80,:207-208,:278-279,:340-341)
+    pins = {"base": -59340.105083 - 32560.139058, "cutoff": -45982, "scale": 0, "mixed": -59340.105083 - 517.98}
+    if which in pins:
+        np.testing.assert_almost_equal(logll, pins[which], decimal=0)
