@@ -19,7 +19,7 @@ using namespace mtrpl;
 struct mtrpl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    SolveTuning tune{0.1, 1e-8, 5e-9, 1e-4, 200000};
+    SolveTuning tune{0.1, 1e-8, 5e-9, 1e-4, 200000, 0.03, 8};
     std::string err;
     // IRF tables resident on the device (mtrpl_irf_tables_upload)
     double *d_irf_tab = nullptr;
@@ -105,7 +105,9 @@ __global__ __launch_bounds__(64) void newton_probe_kernel_r2(const double *par, 
         bl[2 + r] = (i < L) ? b[s * S + L + i] : 0.0;
         bl[4 + r] = (i < L && i > 0) ? b[s * S + 2 * L + i] : 0.0;
     }
+    __shared__ double2 fac_lds[kFactorLdsBytes / 16];
     Factors<2> F;
+    F.lds = fac_lds;
     build_factors(p, yl, cs[s], lane, L, F);
     apply_factors(F, bl, xl, lane, L);
 #pragma unroll
@@ -233,6 +235,8 @@ int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value)
     else if (k == "rtol_floor") ctx->tune.rtol_floor = value;
     else if (k == "atol_rel") ctx->tune.atol_rel = value;
     else if (k == "max_steps") ctx->tune.max_steps = (int)value;
+    else if (k == "rate_max_age") ctx->tune.rate_max_age = (int)value;
+    else if (k == "newton_tol") ctx->tune.newton_tol = value;
     else return bad(ctx, MTRPL_ERR_BAD_ARG, "unknown option");
     return MTRPL_OK;
 }
@@ -246,6 +250,8 @@ int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value)
     else if (k == "rtol_floor") *value = ctx->tune.rtol_floor;
     else if (k == "atol_rel") *value = ctx->tune.atol_rel;
     else if (k == "max_steps") *value = ctx->tune.max_steps;
+    else if (k == "rate_max_age") *value = ctx->tune.rate_max_age;
+    else if (k == "newton_tol") *value = ctx->tune.newton_tol;
     else return MTRPL_ERR_BAD_ARG;
     return MTRPL_OK;
 }

@@ -13,6 +13,8 @@ struct SolveTuning {
     double rtol_floor;  // below ~3e-9 the Newton increments reach the fp64 noise of the flux differences
     double atol_rel;    // internal atol = rtol_int * atol_rel * max(N0, P0 over the film)
     int max_steps;
+    double newton_tol;  // <= 0: SciPy's rule max(10 eps/rtol, min(0.03, sqrt(rtol))); else this value
+    int rate_max_age;   // consecutive 1-iteration Newton solves allowed on a carried-over rate (0: always >= 2)
 };
 
 // RMS norm over the 3nx+1 ODE components; v is already divided by the weights.
@@ -159,7 +161,9 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
     // ---- tolerances (DESIGN.md "error control") ----
     const double rtol = fmax(fmin(tune.rtol_scale * ds.rtol, tune.rtol_cap), tune.rtol_floor);
     const double atol = rtol * tune.atol_rel * dNmax;
-    const double newton_tol = fmax(10.0 * 2.220446049250313e-16 / rtol, fmin(0.03, sqrt(rtol)));
+    const double newton_tol = (tune.newton_tol > 0.0)
+                                  ? tune.newton_tol
+                                  : fmax(10.0 * 2.220446049250313e-16 / rtol, fmin(0.03, sqrt(rtol)));
 
     int n_steps = 0, n_rhs = 0, n_fac = 0, n_jac = 0, n_rej = 0, n_nfail = 0;
     bool clamped = false;
@@ -215,8 +219,12 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
 #pragma unroll
     for (int v = 0; v < V; ++v) yJ[v] = y[v];
     n_jac++;
+    __shared__ double2 fac_lds[kFactorLdsBytes / 16];
     Factors<R> F;
+    F.lds = fac_lds;
     bool have_fac = false;
+    double rate_prev = 1.0;
+    int rate_age = 0;
     int io = 1;
     const double t_end = (nt > 1) ? ts[nt - 1] : 0.0;
 
@@ -224,13 +232,13 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
         if (n_steps >= tune.max_steps) { st = MTRPL_SOLVE_STOPPED_EARLY; break; }
         bool jac_current = (n_steps == 0);
         bool accepted = false;
-        double d[V], yn[V];
+        double d[V], yn[V], isc[V];  // isc: 1/(atol + rtol*|y_predicted|), the error weights of this step
         double err_norm = 0.0, safety = 0.9;
         int attempts = 0;
         while (!accepted) {
             if (++attempts > 60 || !(h > 1e-13 * fmax(t, 1e-3))) { st = MTRPL_SOLVE_STOPPED_EARLY; break; }
             // predictor
-            double yp[V], psi[V], isc[V];
+            double yp[V], psi[V];
 #pragma unroll
             for (int v = 0; v < V; ++v) { yp[v] = D[0][v]; psi[v] = 0.0; }
 #pragma unroll
@@ -240,12 +248,12 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
 #pragma unroll
                     for (int v = 0; v < V; ++v) { yp[v] += D[j][v]; psi[v] += gj * D[j][v]; }
                 }
-            const double ialpha = 1.0 / ndf_alpha(order);
+            const double ialpha = frcp(ndf_alpha(order));
             const double c = h * ialpha;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 psi[v] *= ialpha;
-                isc[v] = 1.0 / (atol + rtol * fabs(yp[v]));
+                isc[v] = frcp(atol + rtol * fabs(yp[v]));
             }
             // simplified Newton
             bool converged = false;
@@ -255,11 +263,12 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
                     build_factors(p, yJ, c, lane, L, F);
                     have_fac = true;
                     n_fac++;
+                    rate_prev = 1.0;  // new matrix: measure the rate afresh
+                    rate_age = 0;
                 }
 #pragma unroll
                 for (int v = 0; v < V; ++v) { d[v] = 0.0; yn[v] = yp[v]; }
                 double dn_old = 0.0;
-                bool bad = false;
                 for (int k = 0; k < 4; ++k) {
                     n_iter = k + 1;
                     rhs_std<R>(p, yn, f, lane, L);
@@ -271,20 +280,26 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
 #pragma unroll
                     for (int v = 0; v < V; ++v) w[v] = dy[v] * isc[v];
                     const double dn = wnorm<V>(w, inv_S);
-                    if (!(dn < 1e300)) { bad = true; break; }  // NaN / inf
-                    double rate = 0.0;
+                    if (!(dn < 1e300)) break;  // NaN / inf
+                    // contraction rate: measured from the 2nd iteration on; for the 1st
+                    // iteration the rate of the previous steps with these same factors
+                    // is carried over (Brown, Byrne & Hindmarsh 1989, VODE "crate")
+                    double rate = rate_prev;
                     if (k > 0) {
-                        rate = dn / dn_old;
+                        rate = dn * frcp(dn_old);
                         double rp = rate;  // rate^(4-k)
                         for (int q = 1; q < 4 - k; ++q) rp *= rate;
-                        if (rate >= 1.0 || rp / (1.0 - rate) * dn > newton_tol) break;
+                        if (rate >= 1.0 || rp * frcp(1.0 - rate) * dn > newton_tol) break;
+                        rate_prev = fmax(0.3 * rate_prev, rate);
+                        rate_age = 0;
                     }
 #pragma unroll
                     for (int v = 0; v < V; ++v) { yn[v] += dy[v]; d[v] += dy[v]; }
-                    if (dn == 0.0 || (k > 0 && rate / (1.0 - rate) * dn < newton_tol)) { converged = true; break; }
+                    const bool rate_ok = (k > 0) || (rate_prev < 0.9 && rate_age < tune.rate_max_age);
+                    if (dn == 0.0 || (rate_ok && rate < 1.0 && rate * frcp(1.0 - rate) * dn < newton_tol)) { converged = true; break; }
                     dn_old = dn;
                 }
-                (void)bad;
+                if (converged && n_iter == 1) rate_age++;
                 if (!converged) {
                     if (jac_current) break;
 #pragma unroll
@@ -305,11 +320,11 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
             safety = 0.9 * (2.0 * 4 + 1) / (2.0 * 4 + n_iter);
             const double ec = ndf_errc(order);
 #pragma unroll
-            for (int v = 0; v < V; ++v) w[v] = ec * d[v] / (atol + rtol * fabs(yn[v]));
+            for (int v = 0; v < V; ++v) w[v] = ec * d[v] * isc[v];
             err_norm = wnorm<V>(w, inv_S);
             if (err_norm > 1.0) {
                 n_rej++;
-                const double fac = fmax(0.2, safety * pow(err_norm, -1.0 / (double)(order + 1)));
+                const double fac = fmax(0.2, safety * inv_root(err_norm, order + 1));
                 h *= fac;
                 change_D<V>(D, order, fac, lane);
                 n_equal = 0;
@@ -342,6 +357,7 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
                 for (int v = 0; v < V; ++v) D[i][v] += D[i + 1][v];
             }
         // dense output (polynomial through the last order+1 steps), forward_solver.py:167
+        const double ih = frcp(h);
         while (io < nt) {
             const double tq = ts[io];
             if (tq > t * (1.0 + 1e-15)) break;
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
 #pragma unroll
             for (int j = 1; j <= 5; ++j)
                 if (j <= order) {
-                    pj *= (tq - (t - (double)(j - 1) * h)) / (h * (double)j);
+                    pj *= (tq - (t - (double)(j - 1) * h)) * ih * (1.0 / (double)j);
 #pragma unroll
                     for (int v = 0; v < V; ++v) yq[v] += D[j][v] * pj;
                 }
@@ -378,16 +394,14 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
         double sm = 0.0, sp = 0.0;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            const double is = 1.0 / (atol + rtol * fabs(D[0][v]));
-            sm += (sel_m[v] * is) * (sel_m[v] * is);
-            sp += (sel_p[v] * is) * (sel_p[v] * is);
+            sm += (sel_m[v] * isc[v]) * (sel_m[v] * isc[v]);
+            sp += (sel_p[v] * isc[v]) * (sel_p[v] * isc[v]);
         }
         const double em = (order > 1) ? ndf_errc(order - 1) * uniform(sqrt(wave_sum(sm) * inv_S)) : 1e300;
         const double ep = (order < 5) ? ndf_errc(order + 1) * uniform(sqrt(wave_sum(sp) * inv_S)) : 1e300;
-        const double tiny = 1e-300;
-        const double fm = pow(fmax(em, tiny), -1.0 / (double)order);
-        const double f0 = pow(fmax(err_norm, tiny), -1.0 / (double)(order + 1));
-        const double fp = pow(fmax(ep, tiny), -1.0 / (double)(order + 2));
+        const double fm = (order > 1) ? inv_root(em, order) : 0.0;
+        const double f0 = inv_root(err_norm, order + 1);
+        const double fp = (order < 5) ? inv_root(ep, order + 2) : 0.0;
         int dorder = 0;
         double fbest = f0;
         if (fm > fbest) { fbest = fm; dorder = -1; }

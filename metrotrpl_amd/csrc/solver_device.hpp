@@ -35,7 +35,7 @@ static constexpr double kKB = 8.61773e-5;
 
 struct Par {
     double n0, p0, mun, mup, ks, Cn, Cp, Sf, Sb, tn, tp, Lam, Tm, kC, Nt, tE;
-    double dx, DnT, DpT, n0p0;
+    double dx, idx, DnT, DpT, n0p0;  // idx = 1/dx
 };
 
 __device__ inline Par make_par(const double *p, double dx)
@@ -47,6 +47,7 @@ __device__ inline Par make_par(const double *p, double dx)
     q.Lam = kQC / (p[MTRPL_P_EPS] * kEps0);  // forward_solver.py:131
     q.Tm = p[MTRPL_P_TM]; q.kC = p[MTRPL_P_KC]; q.Nt = p[MTRPL_P_NT]; q.tE = p[MTRPL_P_TAUE];
     q.dx = dx;
+    q.idx = 1.0 / dx;
     q.DnT = q.mun * kKB * q.Tm;  // mu_n*kB*Tm, left to right as forward_solver.py:357
     q.DpT = q.mup * kKB * q.Tm;
     q.n0p0 = q.n0 * q.p0;
@@ -56,13 +57,6 @@ __device__ inline Par make_par(const double *p, double dx)
 // ---- wave helpers ----------------------------------------------------------
 __device__ inline double shf(double v, int src) { return __shfl(v, src, 64); }
 
-__device__ inline double wave_sum(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
 __device__ inline double uniform(double v)
 {
     // value is identical in all lanes: move it to scalar registers
@@ -71,6 +65,53 @@ __device__ inline double uniform(double v)
     u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
     u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
     return u.d;
+}
+
+// DPP move of a double: lanes whose source is out of range or masked get 0.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ inline double dpp0(double v)
+{
+    union { double d; int i[2]; } u, r;
+    u.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, ROW_MASK, BANK_MASK, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, ROW_MASK, BANK_MASK, false);
+    return r.d;
+}
+
+// Sum over the 64 lanes, result wave-uniform (in SGPRs).  gfx9 DPP ladder:
+// row_shr 1,2,4,8 inside each row of 16, then row_bcast15 / row_bcast31 carry the
+// row totals forward; the grand total lands in lane 63.
+__device__ inline double wave_sum(double v)
+{
+    v += dpp0<0x111>(v);             // row_shr:1
+    v += dpp0<0x112>(v);             // row_shr:2
+    v += dpp0<0x114, 0xf, 0xe>(v);   // row_shr:4, banks 1-3
+    v += dpp0<0x118, 0xf, 0xc>(v);   // row_shr:8, banks 2-3
+    v += dpp0<0x142, 0xa>(v);        // row_bcast:15 -> rows 1,3
+    v += dpp0<0x143, 0xc>(v);        // row_bcast:31 -> rows 2,3
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], 63);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], 63);
+    return u.d;
+}
+
+// x^(-1/k) for step-size factors: 1e-6 relative accuracy is plenty, so use the
+// f32 hardware log2/exp2 instead of a software fp64 pow.
+__device__ inline double inv_root(double x, int k)
+{
+    const float xf = (float)fmin(fmax(x, 1e-30), 1e30);
+    return (double)__builtin_amdgcn_exp2f(-__builtin_amdgcn_logf(xf) / (float)k);
+}
+
+// 1/x by the hardware seed + two Newton steps (~1 ulp; no div_scale/fixup ladder,
+// operands here are always normal, finite and non-zero)
+__device__ inline double frcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
 }
 
 // ---- 2x2 blocks -------------------------------------------------------------
@@ -86,20 +127,16 @@ __device__ inline M2 msub(const M2 &x, const M2 &y) { return M2{x.a - y.a, x.b -
 __device__ inline M2 mneg(const M2 &x) { return M2{-x.a, -x.b, -x.c, -x.d}; }
 __device__ inline M2 minv(const M2 &x)
 {
-    double r = 1.0 / (x.a * x.d - x.b * x.c);
+    const double r = frcp(x.a * x.d - x.b * x.c);
     return M2{x.d * r, -x.b * r, -x.c * r, x.a * r};
 }
 __device__ inline V2 mvec(const M2 &m, const V2 &v) { return V2{m.a * v.x + m.b * v.y, m.c * v.x + m.d * v.y}; }
-__device__ inline M2 mshf(const M2 &m, int src, bool ok)
-{
-    M2 r{shf(m.a, src), shf(m.b, src), shf(m.c, src), shf(m.d, src)};
-    return ok ? r : mzero();
-}
-__device__ inline V2 vshf(const V2 &v, int src, bool ok)
-{
-    V2 r{shf(v.x, src), shf(v.y, src)};
-    return ok ? r : V2{0.0, 0.0};
-}
+// Shuffles wrap around the wave.  No masking is needed anywhere below: every
+// wrapped value is a finite number that only ever meets an exactly-zero
+// coupling block (A of the first rows / C of the last rows vanish, and stay
+// zero through every reduction level), so it contributes exactly 0.
+__device__ inline M2 mshf(const M2 &m, int src) { return M2{shf(m.a, src), shf(m.b, src), shf(m.c, src), shf(m.d, src)}; }
+__device__ inline V2 vshf(const V2 &v, int src) { return V2{shf(v.x, src), shf(v.y, src)}; }
 
 // ---- RHS: forward_solver.py:332-372 (dydt_numba) ------------------------------
 // y[r], y[R+r], y[2R+r] = N_i, P_i, E_i (E on the left face of node i), i = lane*R+r.
@@ -116,10 +153,11 @@ __device__ inline void rhs_std(const Par &p, const double (&y)[3 * R], double (&
         const double N = y[r], P = y[R + r], E = y[2 * R + r];
         const double Nm = (r == 0) ? Nl : y[(r == 0) ? 0 : r - 1];
         const double Pm = (r == 0) ? Pl : y[R + ((r == 0) ? 0 : r - 1)];
-        double jn = p.mun * ((Nm + N) / 2 * E) + p.DnT * ((N - Nm) / p.dx);  // :356-357
-        double jp = p.mup * ((Pm + P) / 2 * E) - p.DpT * ((P - Pm) / p.dx);  // :358-359
+        // :356-359 (x/dx evaluated as x*(1/dx): 1 ulp from the reference's division)
+        double jn = p.mun * ((Nm + N) / 2 * E) + p.DnT * ((N - Nm) * p.idx);
+        double jp = p.mup * ((Pm + P) / 2 * E) - p.DpT * ((P - Pm) * p.idx);
         if (i == 0) {  // :346-351
-            const double Sft = p.Sf * (N * P - p.n0p0) / (N + P);
+            const double Sft = p.Sf * (N * P - p.n0p0) * frcp(N + P);
             jn = Sft;
             jp = -Sft;
         }
@@ -136,14 +174,14 @@ __device__ inline void rhs_std(const Par &p, const double (&y)[3 * R], double (&
         const double NP = N * P - p.n0p0;
         double jnr = Jn[r + 1], jpr = Jp[r + 1];
         if (i == L - 1) {  // :347,:350,:352
-            const double Sbt = p.Sb * NP / (N + P);
+            const double Sbt = p.Sb * NP * frcp(N + P);
             jnr = -Sbt;
             jpr = Sbt;
         }
-        const double recomb = ((p.Cn * N + p.Cp * P) + p.ks + 1 / ((p.tn * P) + (p.tp * N))) * NP;  // :366
+        const double recomb = ((p.Cn * N + p.Cp * P) + p.ks + frcp((p.tn * P) + (p.tp * N))) * NP;  // :366
         const bool real = i < L;
-        f[r] = real ? ((jnr - Jn[r]) / p.dx - recomb) : 0.0;       // :369
-        f[R + r] = real ? (-(jpr - Jp[r]) / p.dx - recomb) : 0.0;  // :370
+        f[r] = real ? ((jnr - Jn[r]) * p.idx - recomb) : 0.0;       // :369
+        f[R + r] = real ? (-(jpr - Jp[r]) * p.idx - recomb) : 0.0;  // :370
         f[2 * R + r] = (real && i > 0) ? (-(Jn[r] + Jp[r]) * p.Lam) : 0.0;  // :363 (edge 0: exactly 0)
     }
 }
@@ -159,16 +197,31 @@ struct Factors<2> {
     double eco[2][4];  // dE_i = bE_i*minv - eco.(dN_{i-1}, dN_i, dP_{i-1}, dP_i)
     double minv[2];
     double cd;         // c/dx
-    M2 Binv_e, BiA_e, BiC_e, cr_al, cr_ga;
-    M2 pal[6], pga[6], Bfin;
+    M2 Bfin;
+    // The 17 elimination blocks (in-lane CR: Binv_e, BiA_e, BiC_e, cr_al, cr_ga; PCR:
+    // al[6], ga[6]) live in this wave's LDS slab: [17 blocks][2 halves][64 lanes] x 16 B,
+    // i.e. every access is a conflict-free ds_read/write_b128 (lane stride 16 B).
+    double2 *lds;
+    enum { BINV_E = 0, BIA_E, BIC_E, CR_AL, CR_GA, PAL0, PGA0 = PAL0 + 6, NBLK = PGA0 + 6 };
+    __device__ inline void put(int blk, int lane, const M2 &m) const
+    {
+        lds[(blk * 2 + 0) * 64 + lane] = double2{m.a, m.b};
+        lds[(blk * 2 + 1) * 64 + lane] = double2{m.c, m.d};
+    }
+    __device__ inline M2 get(int blk, int lane) const
+    {
+        const double2 u = lds[(blk * 2 + 0) * 64 + lane], v = lds[(blk * 2 + 1) * 64 + lane];
+        return M2{u.x, u.y, v.x, v.y};
+    }
 };
+constexpr int kFactorLdsBytes = 17 * 2 * 64 * 16;  // 34816 B per wave
 
 template <int R>
 __device__ inline void edge_blocks(const Par &p, const double (&y)[3 * R], double c, int lane, int L,
                                    M2 (&Lm)[R], M2 (&Rm)[R], Factors<R> &F)
 {
     const double cL = c * p.Lam;
-    const double dnx = p.DnT / p.dx, dpx = p.DpT / p.dx;
+    const double dnx = p.DnT * p.idx, dpx = p.DpT * p.idx;
     const double Nl = shf(y[R - 1], (lane + 63) & 63);
     const double Pl = shf(y[2 * R - 1], (lane + 63) & 63);
 #pragma unroll
@@ -180,14 +233,14 @@ __device__ inline void edge_blocks(const Par &p, const double (&y)[3 * R], doubl
         const double an = 0.5 * p.mun * E, ap = 0.5 * p.mup * E;
         const double jnm = an - dnx, jnp = an + dnx, jpm = ap + dpx, jpp = ap - dpx;
         const double jne = p.mun * 0.5 * (Nm + N), jpe = p.mup * 0.5 * (Pm + P);
-        const double mi = 1.0 / (1.0 + cL * (jne + jpe));
+        const double mi = frcp(1.0 + cL * (jne + jpe));
         const double g = jne * cL * mi, gp = jpe * cL * mi;
         M2 lm{(1.0 - g) * jnm, -g * jpm, -gp * jnm, (1.0 - gp) * jpm};
         M2 rm{(1.0 - g) * jnp, -g * jpp, -gp * jnp, (1.0 - gp) * jpp};
         double w0 = jne * mi, w1 = jpe * mi, mv = mi;
         double e0 = cL * mi * jnm, e1 = cL * mi * jnp, e2 = cL * mi * jpm, e3 = cL * mi * jpp;
         if (i == 0) {  // front surface: J_0 = (S0, -S0), no field
-            const double NP = N * P - p.n0p0, s = N + P, is2 = 1.0 / (s * s);
+            const double NP = N * P - p.n0p0, s = N + P, is2 = frcp(s * s);
             const double s0n = p.Sf * (P * s - NP) * is2, s0p = p.Sf * (N * s - NP) * is2;
             lm = mzero();
             rm = M2{s0n, s0p, -s0n, -s0p};
@@ -212,10 +265,10 @@ template <int R>
 __device__ inline void node_blocks(const Par &p, const double (&y)[3 * R], double c, int lane, int L,
                                    const M2 (&Lm)[R], const M2 (&Rm)[R], M2 (&A)[R], M2 (&B)[R], M2 (&C)[R])
 {
-    const double cd = c / p.dx;
-    const bool has_next = lane < 63;
-    const M2 LmNext = mshf(Lm[0], (lane + 1) & 63, has_next);
-    const M2 RmNext = mshf(Rm[0], (lane + 1) & 63, has_next);
+    const double cd = c * p.idx;
+    // lane 63 wraps to lane 0's edge 0: harmless, its last node is the back surface or padding
+    const M2 LmNext = mshf(Lm[0], (lane + 1) & 63);
+    const M2 RmNext = mshf(Rm[0], (lane + 1) & 63);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = lane * R + r;
@@ -224,12 +277,12 @@ __device__ inline void node_blocks(const Par &p, const double (&y)[3 * R], doubl
         M2 rmn = (r == R - 1) ? RmNext : Rm[(r == R - 1) ? r : r + 1];
         const double NP = N * P - p.n0p0;
         if (i == L - 1) {  // back surface: J_L = (-SL, SL)
-            const double s = N + P, is2 = 1.0 / (s * s);
+            const double s = N + P, is2 = frcp(s * s);
             const double sLn = p.Sb * (P * s - NP) * is2, sLp = p.Sb * (N * s - NP) * is2;
             lmn = M2{-sLn, -sLp, sLn, sLp};
             rmn = mzero();
         }
-        const double den = p.tn * P + p.tp * N, iden = 1.0 / den;
+        const double den = p.tn * P + p.tp * N, iden = frcp(den);
         const double kk = (p.Cn * N + p.Cp * P) + p.ks + iden;
         const double RN = (p.Cn - p.tp * iden * iden) * NP + kk * P;
         const double RP = (p.Cp - p.tn * iden * iden) * NP + kk * N;
@@ -253,34 +306,35 @@ __device__ inline void build_factors(const Par &p, const double (&yJ)[6], double
     M2 Lm[2], Rm[2], A[2], B[2], C[2];
     edge_blocks<2>(p, yJ, c, lane, L, Lm, Rm, F);
     node_blocks<2>(p, yJ, c, lane, L, Lm, Rm, A, B, C);
-    F.cd = c / p.dx;
+    F.cd = c * p.idx;
     // in-lane cyclic reduction: row e = 2*lane (r=0) eliminated, row k = 2*lane+1 (r=1) kept
-    F.Binv_e = minv(B[0]);
-    F.BiA_e = mmul(F.Binv_e, A[0]);
-    F.BiC_e = mmul(F.Binv_e, C[0]);
-    const bool has_next = lane < 63;
+    const M2 Binv_e = minv(B[0]);
+    F.put(Factors<2>::BINV_E, lane, Binv_e);
+    F.put(Factors<2>::BIA_E, lane, mmul(Binv_e, A[0]));
+    F.put(Factors<2>::BIC_E, lane, mmul(Binv_e, C[0]));
     const int nx = (lane + 1) & 63;
-    const M2 Binv_up = mshf(F.Binv_e, nx, has_next);
-    const M2 A_up = mshf(A[0], nx, has_next);
-    const M2 C_up = mshf(C[0], nx, has_next);
-    F.cr_al = mmul(A[1], F.Binv_e);
-    F.cr_ga = mmul(C[1], Binv_up);
-    M2 Ak = mneg(mmul(F.cr_al, A[0]));
-    M2 Ck = mneg(mmul(F.cr_ga, C_up));
-    M2 Bk = msub(msub(B[1], mmul(F.cr_al, C[0])), mmul(F.cr_ga, A_up));
+    const M2 Binv_up = mshf(Binv_e, nx);
+    const M2 A_up = mshf(A[0], nx);
+    const M2 C_up = mshf(C[0], nx);
+    const M2 cr_al = mmul(A[1], Binv_e);
+    const M2 cr_ga = mmul(C[1], Binv_up);
+    F.put(Factors<2>::CR_AL, lane, cr_al);
+    F.put(Factors<2>::CR_GA, lane, cr_ga);
+    M2 Ak = mneg(mmul(cr_al, A[0]));
+    M2 Ck = mneg(mmul(cr_ga, C_up));
+    M2 Bk = msub(msub(B[1], mmul(cr_al, C[0])), mmul(cr_ga, A_up));
     // parallel cyclic reduction over the 64 kept rows
 #pragma unroll
     for (int lv = 0; lv < 6; ++lv) {
         const int s = 1 << lv;
-        const bool okm = lane >= s, okp = lane + s < 64;
         const int lm_ = (lane - s) & 63, lp_ = (lane + s) & 63;
         const M2 Bi = minv(Bk);
-        const M2 Bim = mshf(Bi, lm_, okm), Bip = mshf(Bi, lp_, okp);
-        const M2 Akm = mshf(Ak, lm_, okm), Akp = mshf(Ak, lp_, okp);
-        const M2 Ckm = mshf(Ck, lm_, okm), Ckp = mshf(Ck, lp_, okp);
+        const M2 Bim = mshf(Bi, lm_), Bip = mshf(Bi, lp_);
+        const M2 Akm = mshf(Ak, lm_), Akp = mshf(Ak, lp_);
+        const M2 Ckm = mshf(Ck, lm_), Ckp = mshf(Ck, lp_);
         const M2 al = mmul(Ak, Bim), ga = mmul(Ck, Bip);
-        F.pal[lv] = al;
-        F.pga[lv] = ga;
+        F.put(Factors<2>::PAL0 + lv, lane, al);
+        F.put(Factors<2>::PGA0 + lv, lane, ga);
         Bk = msub(msub(Bk, mmul(al, Ckm)), mmul(ga, Akp));
         Ak = mneg(mmul(al, Akm));
         Ck = mneg(mmul(ga, Ckp));
@@ -292,35 +346,33 @@ __device__ inline void build_factors(const Par &p, const double (&yJ)[6], double
 __device__ inline void apply_factors(const Factors<2> &F, const double (&b)[6], double (&x)[6], int lane, int L)
 {
     const int lnext = (lane + 1) & 63, lprev = (lane + 63) & 63;
-    const bool has_next = lane < 63, has_prev = lane > 0;
     // E-elimination right-hand side
     V2 wb[3];
     wb[0] = V2{F.w[0][0] * b[4], F.w[0][1] * b[4]};
     wb[1] = V2{F.w[1][0] * b[5], F.w[1][1] * b[5]};
-    wb[2] = vshf(wb[0], lnext, has_next);
+    wb[2] = vshf(wb[0], lnext);  // lane 63 wraps to edge 0, whose weights are 0
     V2 r[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int i = lane * 2 + q;
-        V2 nxt = wb[q + 1];
-        if (i >= L - 1) nxt = V2{0.0, 0.0};  // back surface / padding: no field term on the right face
+        const V2 nxt = wb[q + 1];  // edge L and padded edges carry zero weights
         r[q] = V2{b[q] + F.cd * (nxt.x - wb[q].x), b[2 + q] - F.cd * (nxt.y - wb[q].y)};
     }
     // cyclic reduction of the right-hand side
-    const V2 re_up = vshf(r[0], lnext, has_next);
-    const V2 t1 = mvec(F.cr_al, r[0]), t2 = mvec(F.cr_ga, re_up);
+    const V2 re_up = vshf(r[0], lnext);
+    const V2 t1 = mvec(F.get(Factors<2>::CR_AL, lane), r[0]), t2 = mvec(F.get(Factors<2>::CR_GA, lane), re_up);
     V2 rk{r[1].x - t1.x - t2.x, r[1].y - t1.y - t2.y};
 #pragma unroll
     for (int lv = 0; lv < 6; ++lv) {
         const int s = 1 << lv;
-        const V2 rm = vshf(rk, (lane - s) & 63, lane >= s);
-        const V2 rp = vshf(rk, (lane + s) & 63, lane + s < 64);
-        const V2 u1 = mvec(F.pal[lv], rm), u2 = mvec(F.pga[lv], rp);
+        const V2 rm = vshf(rk, (lane - s) & 63);
+        const V2 rp = vshf(rk, (lane + s) & 63);
+        const V2 u1 = mvec(F.get(Factors<2>::PAL0 + lv, lane), rm), u2 = mvec(F.get(Factors<2>::PGA0 + lv, lane), rp);
         rk = V2{rk.x - u1.x - u2.x, rk.y - u1.y - u2.y};
     }
     const V2 xk = mvec(F.Bfin, rk);
-    const V2 xk_prev = vshf(xk, lprev, has_prev);
-    const V2 s0 = mvec(F.Binv_e, r[0]), s1 = mvec(F.BiA_e, xk_prev), s2 = mvec(F.BiC_e, xk);
+    const V2 xk_prev = vshf(xk, lprev);
+    const V2 s0 = mvec(F.get(Factors<2>::BINV_E, lane), r[0]), s1 = mvec(F.get(Factors<2>::BIA_E, lane), xk_prev),
+             s2 = mvec(F.get(Factors<2>::BIC_E, lane), xk);
     const V2 xe{s0.x - s1.x - s2.x, s0.y - s1.y - s2.y};
     x[0] = xe.x; x[1] = xk.x; x[2] = xe.y; x[3] = xk.y;
     // back-substitute the eliminated field unknowns

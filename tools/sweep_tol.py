@@ -23,7 +23,13 @@ def run(verbose=False):
         w6 = max(w6, e[m6].max()); steps += stats[0,0]
         if verbose: print(f"   {key}: e4={e[m4].max():.2e} e6={e[m6].max():.2e} steps={stats[0,0]}")
     return w4, w6, steps/len(cases), who
-for rc, ar in [(1e-8,1e-4),(1e-8,1e-5),(1e-8,1e-6),(3e-9,1e-4),(3e-9,1e-5),(1e-9,1e-4),(1e-9,1e-5),(3e-8,1e-5),(3e-8,1e-6)]:
-    ctx.set_option("rtol_cap", rc); ctx.set_option("atol_rel", ar)
+import itertools
+from metrotrpl_amd import workloads as W
+c2 = W.config2(1024); ix, un = W.indexes(), W.units()
+for ntol, age in [(0.0, 0), (0.0, 8), (1e-3, 8), (1e-2, 8), (3e-2, 8), (1e-1, 8), (3e-2, 50), (1e-1, 50)]:
+    ctx.set_option("newton_tol", ntol); ctx.set_option("rate_max_age", age)
     w4, w6, s, who = run()
-    print(f"rtol_cap={rc:g} atol_rel={ar:g}: worst4={w4:.2e} ({who}) worst6={w6:.2e} mean steps={s:.0f}", flush=True)
+    t0 = time.time()
+    sig, status, stats = batch.solve_batch(c2["states"], ix, un, c2["iniPar"], c2["thickness"], c2["nx"], c2["tSteps"], return_stats=True)
+    dt = time.time() - t0
+    print(f"newton_tol={ntol:g} age={age}: worst4={w4:.2e} ({who}) worst6={w6:.2e} golden steps={s:.0f} | cfg2x1024: {dt*1e3:.1f} ms steps={stats[:,0].mean():.0f} rhs={stats[:,1].mean():.0f} fac={stats[:,2].mean():.0f} nfail={stats[:,5].mean():.1f} bad={int((status!=0).sum())}", flush=True)
