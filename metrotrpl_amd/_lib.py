@@ -114,6 +114,14 @@ def lib():
             if not os.path.exists(LIB_PATH):
                 raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
                                    "g.build()'` (needs hipcc). There is no CPU fallback.")
+            # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7
+            # (same SONAME as /opt/rocm's).  Whichever is loaded first serves every
+            # later NEEDED entry, so let torch (device memory / streams / RCCL
+            # plumbing for bench.py and likelihood.py) bind its runtime first.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
             L = C.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(L, name)

@@ -1,0 +1,119 @@
+"""GPU parity of the fused likelihood path (solve -> IRF -> trim -> ll(T)) against
+(a) the reference's golden log-likelihoods (Tests/test_eval_trial_move.py set-ups,
+captured at the reference's rtol=1e-5: its own pin is decimal=0) and (b) the CPU
+oracle run at tight tolerance on this machine (gate: 1e-6 relative)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+TEMPS = [1.0, 3.0, 7.5, 1000.0]
+
+
+def _setup(which):
+    from tests.test_oracle_solve import _eval_setup
+    ev = np.load(os.path.join(G, "eval.npz"))
+    state, uniq, shared = _eval_setup(ev, which)
+    return ev, state, uniq, shared
+
+
+def _engine(state, uniq, shared):
+    from metrotrpl_amd.likelihood import LikelihoodEngine
+    from metrotrpl_amd import laplace
+    si = shared["_sim_info"]
+    irf_tables, irf_conv = None, shared.get("irf_convolution")
+    if irf_conv is not None:
+        raw = np.load(os.path.join(G, "irf.npz"))["irf745_raw"]
+        irf_tables = laplace.make_I_tables({745: raw})  # built on the device too
+    scale_shift = None
+    fs = shared.get("scale_factor")
+    if fs is not None:
+        pidx = shared["_param_indexes"]
+        scale_shift = []
+        for m in range(si["num_meas"]):
+            g0 = m
+            for grp in fs[2]:
+                if m in grp:
+                    g0 = grp[0]
+            scale_shift.append(np.log10(state[pidx[f"_s{g0}"]]))
+    return LikelihoodEngine(shared["_param_indexes"], shared["units"], si["lengths"], si["nx"][0], si["meas_types"],
+                            shared["_times"], shared["_vals"], shared["_uncs"], uniq["model_uncertainty"],
+                            shared["_init_params"], ini_mode=shared["ini_mode"], hmax=shared["hmax"],
+                            rtol=shared["rtol"], atol=shared["atol"], irf_tables=irf_tables,
+                            irf_convolution=irf_conv, scale_shift=scale_shift)
+
+
+@pytest.mark.parametrize("which", ["base", "cutoff", "scale", "mixed", "irf"])
+def test_loglik_matches_reference_and_oracle(which):
+    from oracle import oracle as O
+    ev, state, uniq, shared = _setup(which)
+    eng = _engine(state, uniq, shared)
+    table = eng.eval(np.asarray(state)[None, :], TEMPS)[0]  # [M, nT]
+    # (a) the reference's golden values (rtol=1e-5 LSODA): its own tests pin decimal=0
+    np.testing.assert_allclose(table[:, 0].sum(), float(ev[which + "__logll_T1"]), rtol=2e-5, atol=1.5)
+    np.testing.assert_allclose(table[:, 1], ev[which + "__ll_meas_T3"], rtol=2e-5, atol=1.0)
+    np.testing.assert_allclose(table[:, 2].sum(), float(ev[which + "__logll_T7p5"]), rtol=2e-5, atol=0.5)
+    # (b) oracle at tight tolerance, every temperature: 1e-6 relative
+    tight = dict(shared, rtol=1e-10, atol=1e-14)
+    _, ref = O.eval_trial_move(state, dict(uniq, _T=1.0), tight, temperatures=TEMPS)
+    scale = np.max(np.abs(ref))
+    # atol: n * (d log10)^2 with d log10 ~ 4e-8 (1e-7 relative on the signal) ~ 2e-12 -- only the
+    # 'scale' set-up (ll ~ 1e-20, i.e. a perfect fit) is anywhere near it
+    np.testing.assert_allclose(table, ref, rtol=1e-6, atol=1e-9 * scale + 1e-10)
+
+
+def test_loglik_batch_of_chains_and_failures():
+    """Many chains at once == one at a time == the oracle; then the failure paths of
+    trial_move_evaluation.py:117-123,:159-165 on hand-made signals."""
+    import ctypes as C
+    import torch
+    from metrotrpl_amd import _lib as L
+    from oracle import oracle as O
+    ev, state, uniq, shared = _setup("irf")
+    eng = _engine(state, uniq, shared)
+    state = np.asarray(state, dtype=float)
+    pidx = shared["_param_indexes"]
+    states = np.stack([state] * 4)
+    states[1, pidx["ks"]] *= 3.0
+    states[2, pidx["ks"]] *= -1.0   # negative PL: clamped to min_y from the first sample on (forward_solver.py:190-192)
+    states[3, pidx["ks"]] *= 0.5
+    t_all = eng.eval(states, TEMPS)
+    tight = dict(shared, rtol=1e-10, atol=1e-14)
+    for c in range(4):
+        one = eng.eval(states[c:c + 1], TEMPS)[0]
+        np.testing.assert_array_equal(one, t_all[c])
+        assert np.all(np.isfinite(one))
+        _, ref = O.eval_trial_move(states[c], dict(uniq, _T=1.0), tight, temperatures=TEMPS)
+        np.testing.assert_allclose(t_all[c], ref, rtol=1e-6)
+    # ll(T) is increasing in T (denominator grows), and ll(T) != ll(1)/T because uncs > 0
+    assert np.all(np.diff(t_all[0], axis=1) > 0)
+    assert not np.allclose(t_all[0][:, 1], t_all[0][:, 0] / 3.0, rtol=1e-5)
+
+    # ---- failure paths, no-IRF engine, signals written by hand into the device buffer ----
+    ev, state, uniq, shared = _setup("base")
+    eng = _engine(state, uniq, shared)
+    eng.upload(np.stack([np.asarray(state, dtype=float)] * 3))
+    T = torch.tensor(TEMPS, dtype=torch.float64, device=eng.dev)
+    eng.launch(T, len(TEMPS))
+    torch.cuda.synchronize()
+    nt = eng.nts[0]
+    sig = eng.d_sig.cpu().numpy().reshape(3, 2, nt).copy()
+    good = sig[0].copy()
+    sig[0, 0, :nt // 4] *= -1          # 25 % negative  -> -inf   (NEGATIVE_FRAC_TOL = 0.2)
+    sig[1, 0, :nt // 10] *= -1         # 10 % negative  -> flipped, finite, same value as the positive trace
+    sig[2, 1, 5] = np.nan              # NaN likelihood -> -inf
+    eng.d_sig.copy_(torch.from_numpy(sig.reshape(-1)))
+    eng.ctx.check(L.lib().mtrpl_loglik_batch_dev(eng.ctx.handle, eng.n_solves, eng.d_like.data_ptr(),
+                                                 eng.d_sig.data_ptr(), eng.d_t.data_ptr(), eng.d_exp_t.data_ptr(),
+                                                 eng.d_exp_y.data_ptr(), eng.d_exp_u.data_ptr(), T.data_ptr(),
+                                                 len(TEMPS), eng.max_nt, eng.d_ll.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    ll = eng.d_ll.cpu().numpy().reshape(3, 2, len(TEMPS))
+    assert np.all(np.isneginf(ll[0, 0])) and np.all(np.isfinite(ll[0, 1]))
+    assert np.all(np.isneginf(ll[2, 1])) and np.all(np.isfinite(ll[2, 0]))
+    ref = O.loglik_tail(good[0], shared["_vals"][0], shared["_uncs"][0], 0.0, 1.0, TEMPS)
+    np.testing.assert_allclose(ll[1, 0], ref, rtol=1e-12)
