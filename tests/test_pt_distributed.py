@@ -1,0 +1,142 @@
+"""CPU-only: the N>1 path of the sharded parallel-tempering ensemble with the
+`gloo` backend (world_size 2 and 3), plus unit tests of the host logic that
+restates metropolis.py:42-90,:129-135 and trial_move_generation.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from metrotrpl_amd import pt, workloads as W  # noqa: E402
+
+
+def _toy_evaluator(states_block, temps):
+    """ll(state, T) = -sum((log10 state - mu)^2) / (T + 0.3): not 1/T-scaling, like the real one."""
+    x = np.log10(np.abs(states_block[:, 1:5]) + 1e-300)
+    e = np.sum((x - np.array([15.5, 1.2, 1.3, -10.3])) ** 2, axis=1)
+    return torch.from_numpy(-e[:, None] * 50.0 / (np.asarray(temps)[None, :] + 0.3))
+
+
+def _proposer():
+    names, ix = W.PARAM_NAMES, W.indexes()
+    active = [n in W.PRIOR_BOX for n in names]
+    prior = {n: W.PRIOR_BOX.get(n, (0, np.inf)) for n in names}
+    do_log = np.ones(len(names), dtype=bool)
+    base = np.where(active, 0.05, 0.0)
+    return lambda s, T, rng: pt.propose(s, T, base, names, active, prior, do_log, ix, rng)
+
+
+def _run_serial(n_chains, iters):
+    ens0 = W.pt_ensemble(n_chains)
+    e = pt.PTEnsemble(ens0["chain_states"], ens0["temperatures"], _toy_evaluator)
+    e.initialise()
+    prop = _proposer()
+    for k in range(1, iters + 1):
+        e.iterate(prop, k % 3 == 0)
+    return e
+
+
+def _worker(rank, world, port, n_chains, iters, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ens0 = W.pt_ensemble(n_chains)
+    e = pt.PTEnsemble(ens0["chain_states"], ens0["temperatures"], _toy_evaluator, rank=rank, world=world)
+    e.initialise()
+    prop = _proposer()
+    for k in range(1, iters + 1):
+        e.iterate(prop, k % 3 == 0)
+    q.put((rank, e.states.copy(), e.logll.copy(), e.swap_accepts.copy(), (e.lo, e.hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,n_chains", [(2, 8), (3, 8)])
+def test_sharded_ensemble_equals_serial(world, n_chains):
+    """Every rank ends with the same replicated ensemble, identical to the 1-rank run
+    (even and uneven chain blocks)."""
+    iters = 9
+    ref = _run_serial(n_chains, iters)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_chains, iters, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=90) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    blocks = sorted(r[4] for r in res)
+    assert blocks == pt.partition(n_chains, world)
+    for _, states, logll, swaps, _ in res:
+        np.testing.assert_array_equal(states, ref.states)
+        np.testing.assert_array_equal(logll, ref.logll)
+        np.testing.assert_array_equal(swaps, ref.swap_accepts)
+    assert ref.swap_attempts.sum() == 3 * (n_chains - 1)
+
+
+def test_partition():
+    assert pt.partition(512, 8) == [(64 * r, 64 * (r + 1)) for r in range(8)]
+    assert pt.partition(8, 3) == [(0, 3), (3, 6), (6, 8)]
+    assert pt.partition(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
+
+
+def test_replica_exchange_matches_reference_rule():
+    """Replay of metropolis.py:129-135 / :66-90 against a direct transcription that
+    carries explicit per-chain ll(T) callables, with the same generator stream."""
+    rng_t = np.random.default_rng(7)
+    n = 6
+    T = W.ladder(n, 50.0)
+    e = rng_t.uniform(10, 200, n)
+    u2 = 0.05
+    ll = lambda c, k: -e[c] / (T[k] + u2)  # noqa: E731
+    table = np.array([[ll(c, k) for k in range(n)] for c in range(n)])
+    owner, att, acc = pt.replica_exchange(table, np.random.default_rng(3))
+    rng = np.random.default_rng(3)
+    who = list(range(n))
+    logll = [ll(c, c) for c in range(n)]
+    for _ in range(n - 1):
+        i = int(rng.integers(0, n - 1))
+        bi_ui, bj_ui = ll(who[i], i), ll(who[i], i + 1)
+        bi_uj, bj_uj = ll(who[i + 1], i), ll(who[i + 1], i + 1)
+        if rng.random() < np.exp(-(bi_ui + bj_uj - bi_uj - bj_ui)):
+            logll[i], logll[i + 1] = bi_uj, bj_ui
+            who[i], who[i + 1] = who[i + 1], who[i]
+    assert list(owner) == who
+    np.testing.assert_array_equal(table[owner, np.arange(n)], logll)
+    assert att.sum() == n - 1 and acc.sum() <= att.sum()
+
+
+def test_propose_respects_box_and_physics():
+    names, ix = W.PARAM_NAMES, W.indexes()
+    active = [n in W.PRIOR_BOX for n in names]
+    prior = {n: W.PRIOR_BOX.get(n, (0, np.inf)) for n in names}
+    states, _ = W.draw_states(64, with_fluence=False)
+    T = W.ladder(64)
+    new = pt.propose(states, T, np.where(active, 0.003, 0.0), names, active, prior, np.ones(len(names), bool), ix,
+                     np.random.default_rng(0))
+    for n_, (lo, hi) in W.PRIOR_BOX.items():
+        assert np.all((new[:, ix[n_]] > lo) & (new[:, ix[n_]] < hi))
+    assert np.all(np.abs(np.log10(new[:, ix["tauN"]]) - np.log10(new[:, ix["tauP"]])) <= 2 + 1e-12)
+    for n_ in ("n0", "eps", "Tm"):
+        np.testing.assert_allclose(new[:, ix[n_]], states[:, ix[n_]], rtol=1e-14)
+    assert np.mean(np.abs(np.log10(new[-1] / states[-1]))[1:11]) > np.mean(np.abs(np.log10(new[0] / states[0]))[1:11])
+    # NaN proposal likelihood is rejected (metropolis.py:49-51)
+    acc = pt.metropolis_accept(np.array([-5.0, -5.0, -5.0]), np.array([np.nan, -np.inf, 10.0]), np.random.default_rng(1))
+    assert list(acc) == [False, False, True]
