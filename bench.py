@@ -122,7 +122,7 @@ def main():
     def step():
         ctx.check(L.lib().mtrpl_solve_batch_dev(ctx.handle, B, d_descs.data_ptr(), d_ini.data_ptr(), d_t.data_ptr(),
                                                 d_out.data_ptr(), d_status.data_ptr(), d_stats.data_ptr(),
-                                                stream.cuda_stream))
+                                                int(c["nx"]), L.MODEL[c["model"]], stream.cuda_stream))
 
     for _ in range(a.warmup):
         step()

@@ -93,9 +93,13 @@ int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value);
 int mtrpl_solve_batch(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *descs,
                       const double *ini, int64_t n_ini, const double *tsteps, int64_t n_t,
                       double *out, int64_t n_out, int32_t *status, int32_t *stats);
+/* Device-resident variant.  The descriptors live in HBM, so the caller states what
+ * the kernel selection needs: max_nx >= every desc's nx (<= 512) and the model all
+ * B descriptors share. */
 int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_descs,
                           const double *d_ini, const double *d_tsteps, double *d_out,
-                          int32_t *d_status, int32_t *d_stats, void *stream);
+                          int32_t *d_status, int32_t *d_stats, int32_t max_nx, int32_t model,
+                          void *stream);
 
 /* ---- a4/a5: RHS of the ODE system (forward_solver.py:332-418) ---------- */
 /* y, dy: [B, S] with S = 3nx+1 (std: N,P,E) or 4nx+1 (traps: N,Ntrap,P,E);

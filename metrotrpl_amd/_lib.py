@@ -64,7 +64,7 @@ SIGNATURES = {
     "mtrpl_get_option": (C.c_int, [_vp, C.c_char_p, _dp]),
     "mtrpl_solve_batch": (C.c_int, [_vp, C.c_int64, _vp, _dp, C.c_int64, _dp, C.c_int64, _dp, C.c_int64,
                                     _ip, _ip]),
-    "mtrpl_solve_batch_dev": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mtrpl_solve_batch_dev": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),
     "mtrpl_rhs_batch": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp]),
     "mtrpl_E_field": (C.c_int, [_vp, C.c_int64, C.c_int32, _dp, _dp, C.c_double, C.c_double, C.c_double,
                                 C.c_double, C.c_double, _dp]),

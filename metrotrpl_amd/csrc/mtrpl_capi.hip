@@ -12,7 +12,7 @@
 
 #include "../../include/metrotrpl_amd.h"
 #include "irf_kernels.hpp"
-#include "solve_kernel.hpp"
+#include "solve_kernel_blk.hpp"
 
 using namespace mtrpl;
 
@@ -27,6 +27,10 @@ struct mtrpl_ctx {
     std::vector<int64_t> irf_off;
     std::vector<double> irf_dt;
     IrfTableSet *d_irf_set = nullptr;
+    // global scratch for the elimination blocks of the 4-wave (nx <= 512) kernel
+    double2 *d_gblk = nullptr;
+    size_t gblk_bytes = 0;
+    int kernel_variant = 0;  // 0: tuned wave kernel for std nx<=128; 1: always the team kernel
 };
 
 #define HIP_TRY(ctx, expr)                                                                   \
@@ -169,8 +173,11 @@ int check_descs(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d, int64_t n_
     for (int64_t s = 0; s < B; ++s) {
         const mtrpl_solve_desc &q = d[s];
         if (q.nx < 2 || q.nt < 1) return bad(ctx, MTRPL_ERR_BAD_ARG, "nx must be >= 2 and nt >= 1");
-        if (q.nx > 128) return bad(ctx, MTRPL_ERR_UNSUPPORTED, "nx > 128 not supported by this build");
-        if (q.model != MTRPL_MODEL_STD) return bad(ctx, MTRPL_ERR_UNSUPPORTED, "only the std model is built");
+        if (q.nx > 512) return bad(ctx, MTRPL_ERR_UNSUPPORTED, "nx > 512 not supported by this build");
+        if (q.model != MTRPL_MODEL_STD && q.model != MTRPL_MODEL_TRAPS)
+            return bad(ctx, MTRPL_ERR_BAD_ARG, "Invalid model");  // forward_solver.py:140
+        if (q.model != d[0].model)
+            return bad(ctx, MTRPL_ERR_UNSUPPORTED, "one batch must use one model (std or traps)");
         if (q.meas != MTRPL_MEAS_TRPL && q.meas != MTRPL_MEAS_TRTS)
             return bad(ctx, MTRPL_ERR_UNSUPPORTED, "TRTS or TRPL only");  // forward_solver.py:203
         if (q.ini_mode != MTRPL_INI_DENSITY && q.ini_mode != MTRPL_INI_FLUENCE)
@@ -185,6 +192,57 @@ int check_descs(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d, int64_t n_
             return bad(ctx, MTRPL_ERR_BAD_ARG, "thickness, hmax, rtol must be positive");
     }
     return MTRPL_OK;
+}
+
+// forward_solver.py:332-418 through the team RHS (any nx <= 128*W, std or traps);
+// reference layouts: std [N(L),P(L),E(L+1)], traps [N(L),Ntrap(L),P(L),E(L+1)]
+template <int W, bool TRAPS>
+__global__ __launch_bounds__(64 * W) void rhs_batch_kernel_blk(const double *par, const double *dxs, const double *y,
+                                                               double *dy, int nx, int64_t B)
+{
+    constexpr int V = TRAPS ? 8 : 6;
+    const int64_t s = blockIdx.x;
+    if (s >= B) return;
+    __shared__ double2 xbuf_lds[team_xbuf_bytes<W>() / 16];
+    __shared__ double rbuf_lds[5 * W + 4];
+    Team<W> tm;
+    tm.tid = threadIdx.x; tm.lane = threadIdx.x & 63; tm.wave = threadIdx.x >> 6;
+    tm.xbuf = xbuf_lds; tm.rbuf = rbuf_lds; tm.xpar = 0; tm.rpar = 0;
+    const int L = nx, S = (TRAPS ? 4 : 3) * nx + 1;
+    const int oP = (TRAPS ? 2 : 1) * L, oE = (TRAPS ? 3 : 2) * L;
+    const Par p = make_par(par + 16 * s, dxs[s]);
+    const double *ys = y + s * S;
+    double *fs = dy + s * S;
+    double yl[V], fl[V];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = tm.tid * 2 + r;
+        yl[r] = (i < L) ? ys[i] : 1.0;
+        yl[2 + r] = (i < L) ? ys[oP + i] : 1.0;
+        yl[4 + r] = (i < L) ? ys[oE + i] : 0.0;
+        if (TRAPS) yl[6 + r] = (i < L) ? ys[L + i] : 0.0;
+    }
+    team_rhs<W, TRAPS>(tm, p, yl, fl, L);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = tm.tid * 2 + r;
+        if (i < L) {
+            fs[i] = fl[r];
+            fs[oP + i] = fl[2 + r];
+            fs[oE + i] = fl[4 + r];
+            if (TRAPS) fs[L + i] = fl[6 + r];
+        }
+    }
+    if (tm.tid == 0) fs[oE + L] = 0.0;  // dE_L = 0 (forward_solver.py:350-352,:363)
+}
+
+template <int W, bool TRAPS, bool GBLK>
+void launch_blk(hipStream_t s, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
+                const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats,
+                const SolveTuning &tune, double2 *gblk)
+{
+    hipLaunchKernelGGL((solve_kernel_blk<W, TRAPS, GBLK>), dim3((unsigned)B), dim3(64 * W), 0, s, d_descs, d_ini,
+                       d_tsteps, d_out, d_status, d_stats, B, tune, gblk);
 }
 
 }  // namespace
@@ -219,6 +277,7 @@ int mtrpl_ctx_destroy(mtrpl_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->d_irf_tab) (void)hipFree(ctx->d_irf_tab);
     if (ctx->d_irf_set) (void)hipFree(ctx->d_irf_set);
+    if (ctx->d_gblk) (void)hipFree(ctx->d_gblk);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return MTRPL_OK;
@@ -237,6 +296,7 @@ int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value)
     else if (k == "max_steps") ctx->tune.max_steps = (int)value;
     else if (k == "rate_max_age") ctx->tune.rate_max_age = (int)value;
     else if (k == "newton_tol") ctx->tune.newton_tol = value;
+    else if (k == "kernel_variant") ctx->kernel_variant = (int)value;
     else return bad(ctx, MTRPL_ERR_BAD_ARG, "unknown option");
     return MTRPL_OK;
 }
@@ -252,20 +312,52 @@ int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value)
     else if (k == "max_steps") *value = ctx->tune.max_steps;
     else if (k == "rate_max_age") *value = ctx->tune.rate_max_age;
     else if (k == "newton_tol") *value = ctx->tune.newton_tol;
+    else if (k == "kernel_variant") *value = ctx->kernel_variant;
     else return MTRPL_ERR_BAD_ARG;
     return MTRPL_OK;
 }
 
 int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
-                          const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats, void *stream)
+                          const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats, int32_t max_nx,
+                          int32_t model, void *stream)
 {
     if (!ctx) return MTRPL_ERR_BAD_ARG;
     if (B <= 0) return MTRPL_OK;
     if (!d_descs || !d_tsteps || !d_out || !d_status) return bad(ctx, MTRPL_ERR_BAD_ARG, "null device pointer");
+    if (max_nx < 2 || max_nx > 512) return bad(ctx, MTRPL_ERR_UNSUPPORTED, "nx > 512 not supported by this build");
+    if (model != MTRPL_MODEL_STD && model != MTRPL_MODEL_TRAPS) return bad(ctx, MTRPL_ERR_BAD_ARG, "Invalid model");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;  // exactly the caller's stream (NULL = the default stream)
-    hipLaunchKernelGGL(solve_kernel_r2, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out, d_status,
-                       d_stats, B, ctx->tune);
+    const bool traps = model == MTRPL_MODEL_TRAPS;
+    if (max_nx <= 128) {
+        if (!traps && ctx->kernel_variant == 0)
+            hipLaunchKernelGGL(solve_kernel_r2, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
+                               d_status, d_stats, B, ctx->tune);
+        else if (!traps)
+            launch_blk<1, false, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr);
+        else
+            launch_blk<1, true, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr);
+    } else if (max_nx <= 256) {
+        if (!traps)
+            launch_blk<2, false, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr);
+        else
+            launch_blk<2, true, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr);
+    } else {
+        // 4 waves per solve: the 21 elimination blocks per thread (172 KB per solve) do not fit
+        // in LDS next to the exchange buffers -> per-solve slab in HBM (L2/MALL-resident)
+        const size_t need = (size_t)B * team_blk_bytes<4>();
+        if (need > ctx->gblk_bytes) {
+            if (ctx->d_gblk) (void)hipFree(ctx->d_gblk);
+            ctx->d_gblk = nullptr;
+            ctx->gblk_bytes = 0;
+            HIP_TRY(ctx, hipMalloc((void **)&ctx->d_gblk, need));
+            ctx->gblk_bytes = need;
+        }
+        if (!traps)
+            launch_blk<4, false, true>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, ctx->d_gblk);
+        else
+            launch_blk<4, true, true>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, ctx->d_gblk);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return MTRPL_OK;
 }
@@ -291,8 +383,10 @@ int mtrpl_solve_batch(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *descs, 
     if (n_ini > 0 && ini) HIP_TRY(ctx, hipMemcpyAsync(di.p, ini, sizeof(double) * (size_t)n_ini, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(dt.p, tsteps, sizeof(double) * (size_t)n_t, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(dout.p, 0, sizeof(double) * (size_t)n_out, s));
+    int32_t max_nx = 0;
+    for (int64_t k = 0; k < B; ++k) max_nx = std::max(max_nx, descs[k].nx);
     rc = mtrpl_solve_batch_dev(ctx, B, dd.as<mtrpl_solve_desc>(), di.as<double>(), dt.as<double>(), dout.as<double>(),
-                               dst.as<int32_t>(), dstat.as<int32_t>(), s);
+                               dst.as<int32_t>(), dstat.as<int32_t>(), max_nx, descs[0].model, s);
     if (rc != MTRPL_OK) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipMemcpyAsync(status, dst.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
@@ -307,10 +401,11 @@ int mtrpl_rhs_batch(mtrpl_ctx *ctx, int64_t B, int32_t nx, int32_t model, const 
     if (!ctx) return MTRPL_ERR_BAD_ARG;
     if (B <= 0) return MTRPL_OK;
     if (!par || !dx || !y || !dy || nx < 2) return bad(ctx, MTRPL_ERR_BAD_ARG, "bad argument");
-    if (model != MTRPL_MODEL_STD) return bad(ctx, MTRPL_ERR_UNSUPPORTED, "only the std model is built");
-    if (nx > 128) return bad(ctx, MTRPL_ERR_UNSUPPORTED, "nx > 128 not supported by this build");
+    if (model != MTRPL_MODEL_STD && model != MTRPL_MODEL_TRAPS) return bad(ctx, MTRPL_ERR_BAD_ARG, "Invalid model");
+    if (nx > 512) return bad(ctx, MTRPL_ERR_UNSUPPORTED, "nx > 512 not supported by this build");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t S = 3 * (size_t)nx + 1;
+    const bool traps = model == MTRPL_MODEL_TRAPS;
+    const size_t S = (traps ? 4 : 3) * (size_t)nx + 1;
     DevBuf dp, ddx, dy_in, dy_out;
     HIP_TRY(ctx, dp.alloc(sizeof(double) * 16 * B));
     HIP_TRY(ctx, ddx.alloc(sizeof(double) * B));
@@ -320,8 +415,16 @@ int mtrpl_rhs_batch(mtrpl_ctx *ctx, int64_t B, int32_t nx, int32_t model, const 
     HIP_TRY(ctx, hipMemcpyAsync(dp.p, par, sizeof(double) * 16 * B, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(ddx.p, dx, sizeof(double) * B, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(dy_in.p, y, sizeof(double) * S * B, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(rhs_batch_kernel_r2, dim3((unsigned)B), dim3(64), 0, s, dp.as<double>(), ddx.as<double>(),
-                       dy_in.as<double>(), dy_out.as<double>(), nx, B);
+#define MTRPL_RHS_LAUNCH(W_, T_)                                                                                  \
+    hipLaunchKernelGGL((rhs_batch_kernel_blk<W_, T_>), dim3((unsigned)B), dim3(64 * W_), 0, s, dp.as<double>(), \
+                       ddx.as<double>(), dy_in.as<double>(), dy_out.as<double>(), nx, B)
+    if (nx <= 128 && !traps && ctx->kernel_variant == 0)
+        hipLaunchKernelGGL(rhs_batch_kernel_r2, dim3((unsigned)B), dim3(64), 0, s, dp.as<double>(), ddx.as<double>(),
+                           dy_in.as<double>(), dy_out.as<double>(), nx, B);
+    else if (nx <= 128) { if (traps) MTRPL_RHS_LAUNCH(1, true); else MTRPL_RHS_LAUNCH(1, false); }
+    else if (nx <= 256) { if (traps) MTRPL_RHS_LAUNCH(2, true); else MTRPL_RHS_LAUNCH(2, false); }
+    else { if (traps) MTRPL_RHS_LAUNCH(4, true); else MTRPL_RHS_LAUNCH(4, false); }
+#undef MTRPL_RHS_LAUNCH
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(dy, dy_out.p, sizeof(double) * S * B, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));

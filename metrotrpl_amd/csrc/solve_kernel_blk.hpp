@@ -1,0 +1,406 @@
+// solve_kernel_blk.hpp -- the batched forward-solve kernel, generalised: W wavefronts
+// per solve (nx <= 128*W), std or traps model.  Same algorithm and the same
+// reference mapping as solve_kernel.hpp (forward_solver.py:41-203); the device
+// functions are in solver_block.hpp.
+#pragma once
+#include "solve_kernel.hpp"
+#include "solver_block.hpp"
+
+namespace mtrpl {
+
+template <int W, bool TRAPS, bool GBLK>
+__global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_desc *__restrict__ descs,
+                                                           const double *__restrict__ ini,
+                                                           const double *__restrict__ tsteps,
+                                                           double *__restrict__ out, int32_t *__restrict__ status,
+                                                           int32_t *__restrict__ stats, int64_t B, SolveTuning tune,
+                                                           double2 *__restrict__ gblk)
+{
+    constexpr int R = 2, V = TRAPS ? 8 : 6, T = Team<W>::T;
+    const int64_t sidx = blockIdx.x;
+    if (sidx >= B) return;
+    const int lane = threadIdx.x & 63, tid = threadIdx.x;
+    __shared__ double2 xbuf_lds[team_xbuf_bytes<W>() / 16];
+    __shared__ double rbuf_lds[4 * W + W + 4];
+    __shared__ double2 blk_lds[GBLK ? 1 : team_blk_bytes<W>() / 16];
+    Team<W> tm;
+    tm.tid = tid; tm.lane = lane; tm.wave = tid >> 6;
+    tm.xbuf = xbuf_lds; tm.rbuf = rbuf_lds; tm.xpar = 0; tm.rpar = 0;
+    auto tnorm = [&](const double (&v)[V], double inv_S_) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < V; ++k) s += v[k] * v[k];
+        return sqrt(team_sum<W>(tm, s) * inv_S_);
+    };
+    const mtrpl_solve_desc &ds = descs[sidx];
+    const int L = ds.nx, nt = ds.nt, meas = ds.meas;
+    const double dx = ds.thickness / (double)L;  // sim_utils.py:265
+    const Par p = make_par(ds.par, dx);
+    const double *ts = tsteps + ds.t_off;
+    double *o = out + ds.out_off;
+    const double sig_scale = (meas == MTRPL_MEAS_TRPL) ? 1e23 : 1e9;  // forward_solver.py:189,:197
+    const double min_y = ds.min_y;
+    const double hmax = ds.hmax;
+    const double inv_S = 1.0 / (double)((TRAPS ? 4 : 3) * L + 1);
+
+    // ---- initial condition, forward_solver.py:100-122 ----
+    double y[V];
+    double dNmax = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid * R + r;
+        double dN = 0.0;
+        if (i < L) {
+            if (ds.ini_mode == MTRPL_INI_DENSITY) {
+                dN = ini[ds.ini_off + i] * 1e-21;  // :102
+            } else {
+                const double fluence = ds.ini[0] * 1e-14, alpha = ds.ini[1] * 1e-7;  // :107-108
+                const int ii = ((int)ds.ini[2] < 0) ? (L - 1 - i) : i;               // :111
+                // np.linspace(dx/2, thickness - dx/2, nx)[ii]  (sim_utils.py:266)
+                const double x0 = dx / 2, x1 = ds.thickness - dx / 2;
+                const double step = (x1 - x0) / (double)(L - 1);
+                const double x = (ii == L - 1) ? x1 : x0 + (double)ii * step;
+                dN = fluence * alpha * exp(-alpha * x);  // :109
+            }
+        }
+        y[r] = (i < L) ? dN + p.n0 : 1.0;       // :120
+        y[R + r] = (i < L) ? dN + p.p0 : 1.0;   // :121
+        if (TRAPS) y[6 + r] = 0.0;              // :133 np.zeros_like(N)
+        dNmax = fmax(dNmax, (i < L) ? fmax(y[r], y[R + r]) : 0.0);
+    }
+    {
+        // E_field (:26-38, :122): E_i = Lambda*dx*cumsum((P-p0)-(N-n0))[i-1]; prefix scan over the team
+        double own[R], run = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = tid * R + r;
+            own[r] = (i < L) ? ((y[R + r] - p.p0) - (y[r] - p.n0)) : 0.0;
+            run += own[r];
+        }
+        double incl = run;  // inclusive scan of per-thread totals inside the wave
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const double t = shf(incl, (lane - s) & 63);
+            incl += (lane >= s) ? t : 0.0;
+        }
+        double excl = incl - run;
+        if (W > 1) {  // add the totals of the waves to the left
+            double *r_ = tm.rbuf + 2 * W * 2;
+            if (lane == 63) r_[tm.wave] = incl;
+            __syncthreads();
+            for (int w_ = 0; w_ < W; ++w_)
+                if (w_ < tm.wave) excl += r_[w_];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = tid * R + r;
+            y[2 * R + r] = (i > 0 && i < L) ? p.Lam * dx * excl : 0.0;
+            excl += own[r];
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) dNmax = fmax(dNmax, __shfl_xor(dNmax, s, 64));
+    if (W > 1) {
+        double *r_ = tm.rbuf + 2 * W * 2;
+        if (lane == 0) r_[tm.wave] = dNmax;
+        __syncthreads();
+        for (int w_ = 0; w_ < W; ++w_) dNmax = fmax(dNmax, r_[w_]);
+        __syncthreads();
+    }
+    auto sigof = [&](const double (&yy)[V]) {
+        // dx * sum ks (N P - n0 p0) (forward_solver.py:228-236,:258-269) or
+        // dx * sum q_C (mu_n (N-n0) + mu_p (P-p0)) (:239-247,:272-274)
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = tid * R + r;
+            const double N = yy[r], P = yy[R + r];
+            const double v = (meas == MTRPL_MEAS_TRPL) ? p.ks * (N * P - p.n0p0)
+                                                       : kQC * (p.mun * (N - p.n0) + p.mup * (P - p.p0));
+            s += (i < L) ? v : 0.0;
+        }
+        return team_sum<W>(tm, s) * p.dx * sig_scale;
+    };
+
+    // ---- tolerances (DESIGN.md "error control") ----
+    const double rtol = fmax(fmin(tune.rtol_scale * ds.rtol, tune.rtol_cap), tune.rtol_floor);
+    const double atol = rtol * tune.atol_rel * dNmax;
+    const double newton_tol = (tune.newton_tol > 0.0)
+                                  ? tune.newton_tol
+                                  : fmax(10.0 * 2.220446049250313e-16 / rtol, fmin(0.03, sqrt(rtol)));
+
+    int n_steps = 0, n_rhs = 0, n_fac = 0, n_jac = 0, n_rej = 0, n_nfail = 0;
+    bool clamped = false;
+    int st = MTRPL_SOLVE_OK;
+
+    auto emit = [&](int k, double v) {
+        // forward_solver.py:190-192: from the first sample below min_y onward -> min_y
+        if (!clamped && v < min_y) clamped = true;
+        if (clamped) v = min_y;
+        if (tid == 0) o[k] = v;
+    };
+
+    emit(0, sigof(y));
+
+    double D[8][V];
+    double f[V], w[V];
+    team_rhs<W, TRAPS>(tm, p, y, f, L);
+    n_rhs++;
+
+    // ---- initial step (Hairer, Norsett & Wanner I, II.4, first-order variant) ----
+    double h;
+    {
+#pragma unroll
+        for (int v = 0; v < V; ++v) w[v] = y[v] / (atol + rtol * fabs(y[v]));
+        const double d0 = tnorm(w, inv_S);
+#pragma unroll
+        for (int v = 0; v < V; ++v) w[v] = f[v] / (atol + rtol * fabs(y[v]));
+        const double d1 = tnorm(w, inv_S);
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        double y1[V], f1[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) y1[v] = y[v] + h0 * f[v];
+        team_rhs<W, TRAPS>(tm, p, y1, f1, L);
+        n_rhs++;
+#pragma unroll
+        for (int v = 0; v < V; ++v) w[v] = (f1[v] - f[v]) / (atol + rtol * fabs(y[v]));
+        const double d2 = tnorm(w, inv_S) / h0;
+        const double dm = fmax(d1, d2);
+        const double h1 = (dm <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : sqrt(0.01 / dm);
+        h = fmin(fmin(100.0 * h0, h1), hmax);
+        if (nt > 1) h = fmin(h, ts[nt - 1]);
+        if (!(h > 0.0)) h = 1e-9;
+    }
+
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int v = 0; v < V; ++v) D[k][v] = (k == 0) ? y[v] : ((k == 1) ? h * f[v] : 0.0);
+
+    int order = 1, n_equal = 0;
+    double t = 0.0;
+    double yJ[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) yJ[v] = y[v];
+    n_jac++;
+    TeamFactors<W, TRAPS> F;
+    F.blk = GBLK ? (gblk + (size_t)sidx * (team_blk_bytes<W>() / 16)) : blk_lds;
+    bool have_fac = false;
+    double rate_prev = 1.0;
+    int rate_age = 0;
+    int io = 1;
+    const double t_end = (nt > 1) ? ts[nt - 1] : 0.0;
+
+    while (io < nt) {
+        if (n_steps >= tune.max_steps) { st = MTRPL_SOLVE_STOPPED_EARLY; break; }
+        bool jac_current = (n_steps == 0);
+        bool accepted = false;
+        double d[V], yn[V], isc[V];  // isc: 1/(atol + rtol*|y_predicted|), the error weights of this step
+        double err_norm = 0.0, safety = 0.9;
+        int attempts = 0;
+        while (!accepted) {
+            if (++attempts > 60 || !(h > 1e-13 * fmax(t, 1e-3))) { st = MTRPL_SOLVE_STOPPED_EARLY; break; }
+            // predictor
+            double yp[V], psi[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) { yp[v] = D[0][v]; psi[v] = 0.0; }
+#pragma unroll
+            for (int j = 1; j <= 5; ++j)
+                if (j <= order) {
+                    const double gj = ndf_gamma(j);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) { yp[v] += D[j][v]; psi[v] += gj * D[j][v]; }
+                }
+            const double ialpha = frcp(ndf_alpha(order));
+            const double c = h * ialpha;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                psi[v] *= ialpha;
+                isc[v] = frcp(atol + rtol * fabs(yp[v]));
+            }
+            // simplified Newton
+            bool converged = false;
+            int n_iter = 0;
+            while (!converged) {
+                if (!have_fac) {
+                    team_build<W, TRAPS>(tm, p, yJ, c, L, F);
+                    have_fac = true;
+                    n_fac++;
+                    rate_prev = 1.0;  // new matrix: measure the rate afresh
+                    rate_age = 0;
+                }
+#pragma unroll
+                for (int v = 0; v < V; ++v) { d[v] = 0.0; yn[v] = yp[v]; }
+                double dn_old = 0.0;
+                for (int k = 0; k < 4; ++k) {
+                    n_iter = k + 1;
+                    team_rhs<W, TRAPS>(tm, p, yn, f, L);
+                    n_rhs++;
+                    double b[V], dy[V];
+#pragma unroll
+                    for (int v = 0; v < V; ++v) b[v] = c * f[v] - psi[v] - d[v];
+                    team_apply<W, TRAPS>(tm, F, b, dy);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) w[v] = dy[v] * isc[v];
+                    const double dn = tnorm(w, inv_S);
+                    if (!(dn < 1e300)) break;  // NaN / inf
+                    // contraction rate: measured from the 2nd iteration on; for the 1st
+                    // iteration the rate of the previous steps with these same factors
+                    // is carried over (Brown, Byrne & Hindmarsh 1989, VODE "crate")
+                    double rate = rate_prev;
+                    if (k > 0) {
+                        rate = dn * frcp(dn_old);
+                        double rp = rate;  // rate^(4-k)
+                        for (int q = 1; q < 4 - k; ++q) rp *= rate;
+                        if (rate >= 1.0 || rp * frcp(1.0 - rate) * dn > newton_tol) break;
+                        rate_prev = fmax(0.3 * rate_prev, rate);
+                        rate_age = 0;
+                    }
+#pragma unroll
+                    for (int v = 0; v < V; ++v) { yn[v] += dy[v]; d[v] += dy[v]; }
+                    const bool rate_ok = (k > 0) || (rate_prev < 0.9 && rate_age < tune.rate_max_age);
+                    if (dn == 0.0 || (rate_ok && rate < 1.0 && rate * frcp(1.0 - rate) * dn < newton_tol)) { converged = true; break; }
+                    dn_old = dn;
+                }
+                if (converged && n_iter == 1) rate_age++;
+                if (!converged) {
+                    if (jac_current) break;
+#pragma unroll
+                    for (int v = 0; v < V; ++v) yJ[v] = yp[v];
+                    n_jac++;
+                    jac_current = true;
+                    have_fac = false;
+                }
+            }
+            if (!converged) {
+                n_nfail++;
+                h *= 0.5;
+                change_D<V>(D, order, 0.5, lane);
+                n_equal = 0;
+                have_fac = false;
+                continue;
+            }
+            safety = 0.9 * (2.0 * 4 + 1) / (2.0 * 4 + n_iter);
+            const double ec = ndf_errc(order);
+#pragma unroll
+            for (int v = 0; v < V; ++v) w[v] = ec * d[v] * isc[v];
+            err_norm = tnorm(w, inv_S);
+            if (err_norm > 1.0) {
+                n_rej++;
+                const double fac = fmax(0.2, safety * inv_root(err_norm, order + 1));
+                h *= fac;
+                change_D<V>(D, order, fac, lane);
+                n_equal = 0;
+                have_fac = false;
+            } else {
+                accepted = true;
+            }
+        }
+        if (!accepted) break;
+        n_steps++;
+        n_equal++;
+        t += h;
+        // update differences: D[order+2] = d - D[order+1]; D[order+1] = d; D[i] += D[i+1]
+#pragma unroll
+        for (int k = 2; k < 8; ++k)
+            if (k == order + 2) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) D[k][v] = d[v] - D[k - 1][v];
+            }
+#pragma unroll
+        for (int k = 1; k < 7; ++k)
+            if (k == order + 1) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) D[k][v] = d[v];
+            }
+#pragma unroll
+        for (int i = 5; i >= 0; --i)
+            if (i <= order) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) D[i][v] += D[i + 1][v];
+            }
+        // dense output (polynomial through the last order+1 steps), forward_solver.py:167
+        const double ih = frcp(h);
+        while (io < nt) {
+            const double tq = ts[io];
+            if (tq > t * (1.0 + 1e-15)) break;
+            double yq[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) yq[v] = D[0][v];
+            double pj = 1.0;
+#pragma unroll
+            for (int j = 1; j <= 5; ++j)
+                if (j <= order) {
+                    pj *= (tq - (t - (double)(j - 1) * h)) * ih * (1.0 / (double)j);
+#pragma unroll
+                    for (int v = 0; v < V; ++v) yq[v] += D[j][v] * pj;
+                }
+            emit(io, sigof(yq));
+            io++;
+        }
+        if (n_equal < order + 1) continue;
+        // order / step-size selection
+        double sel_m[V], sel_p[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) { sel_m[v] = 0.0; sel_p[v] = 0.0; }
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            if (k == order) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) sel_m[v] = D[k][v];
+            }
+            if (k == order + 2) {
+#pragma unroll
+                for (int v = 0; v < V; ++v) sel_p[v] = D[k][v];
+            }
+        }
+        double sm = 0.0, sp = 0.0;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            sm += (sel_m[v] * isc[v]) * (sel_m[v] * isc[v]);
+            sp += (sel_p[v] * isc[v]) * (sel_p[v] * isc[v]);
+        }
+        team_sum2<W>(tm, sm, sp);
+        const double em = (order > 1) ? ndf_errc(order - 1) * sqrt(sm * inv_S) : 1e300;
+        const double ep = (order < 5) ? ndf_errc(order + 1) * sqrt(sp * inv_S) : 1e300;
+        const double fm = (order > 1) ? inv_root(em, order) : 0.0;
+        const double f0 = inv_root(err_norm, order + 1);
+        const double fp = (order < 5) ? inv_root(ep, order + 2) : 0.0;
+        int dorder = 0;
+        double fbest = f0;
+        if (fm > fbest) { fbest = fm; dorder = -1; }
+        if (fp > fbest) { fbest = fp; dorder = 1; }
+        double fac = fmin(10.0, safety * fbest);
+        if (h * fac > hmax) fac = hmax / h;
+        if (dorder == 0 && fac >= 0.9 && fac < 1.2) {
+            n_equal = order;  // keep h and the factors; test again after the next step
+            continue;
+        }
+        order += dorder;
+        h *= fac;
+        change_D<V>(D, order, fac, lane);
+        n_equal = 0;
+        have_fac = false;
+    }
+
+    if (st != MTRPL_SOLVE_OK) {
+        // forward_solver.py:168: samples after the last solved time come from a zeroed state
+        double z[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) z[v] = 0.0;
+        const double zs = sigof(z);
+        for (; io < nt; ++io) emit(io, zs);
+    }
+    (void)t_end;
+    if (tid == 0) {
+        status[sidx] = st;
+        if (stats) {
+            int32_t *s = stats + 8 * sidx;
+            s[0] = n_steps; s[1] = n_rhs; s[2] = n_fac; s[3] = n_jac;
+            s[4] = n_rej; s[5] = n_nfail; s[6] = order; s[7] = 0;
+        }
+    }
+}
+
+}  // namespace mtrpl

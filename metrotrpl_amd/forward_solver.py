@@ -105,4 +105,12 @@ def solve(iniPar, g, state, indexes, meas="TRPL", units=None, solver=("solveivp"
     return sig
 
 
-MODELS = {"std": dydt_numba}
+def dydt_numba_traps(t, y, L_, dx, N0, P0, mu_n, mu_p, r_rad, CN, CP, sr0, srL, tauN, tauP, Lambda, Tm, kC, Nt,
+                     tauE):
+    """forward_solver.py:374-418 on the device (one state, y = [N, N_trap, P, E])."""
+    par = np.array([[N0, P0, mu_n, mu_p, r_rad, CN, CP, sr0, srL, tauN, tauP, q_C / (Lambda * eps0), Tm,
+                     kC, Nt, tauE]])
+    return batch.rhs_batch(par, [dx], np.asarray(y, dtype=np.float64)[None, :], L_, model="traps")[0]
+
+
+MODELS = {"std": dydt_numba, "traps": dydt_numba_traps}

@@ -113,7 +113,7 @@ class LikelihoodEngine:
         lib, h = L.lib(), self.ctx.handle
         self.ctx.check(lib.mtrpl_solve_batch_dev(h, self.n_solves, self.d_descs.data_ptr(), self.d_ini.data_ptr(),
                                                  self.d_t.data_ptr(), self.d_sig.data_ptr(), self.d_status.data_ptr(),
-                                                 self.d_stats.data_ptr(), s))
+                                                 self.d_stats.data_ptr(), self.nx, L.MODEL[self.model], s))
         self.ctx.check(lib.mtrpl_loglik_batch_dev(h, self.n_solves, self.d_like.data_ptr(), self.d_sig.data_ptr(),
                                                   self.d_t.data_ptr(), self.d_exp_t.data_ptr(), self.d_exp_y.data_ptr(),
                                                   self.d_exp_u.data_ptr(), d_T.data_ptr(), nT, self.max_nt,

@@ -1,0 +1,129 @@
+"""GPU parity of the generalised 'team' kernels (W waves per solve): traps model
+(forward_solver.py:374-418), nx up to 512 (BASELINE.json configs[4]), and the W=1
+team kernel against the tuned wave kernel."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+REL_TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(G, "solve.npz"))
+
+
+@pytest.fixture(scope="module")
+def conv():
+    return np.load(os.path.join(G, "solve_converged.npz"))
+
+
+def _relerr(sig, ref, floor=1e-4):
+    m = np.abs(ref) >= floor * np.abs(ref[0])
+    return np.max(np.abs(sig[m] - ref[m]) / np.abs(ref[m]))
+
+
+def test_rhs_all_sizes_and_traps():
+    """dydt_numba and dydt_numba_traps on the reference's random states, L = 8 ... 512."""
+    from metrotrpl_amd import batch
+    from metrotrpl_amd.forward_solver import q_C, eps0
+    rhsg = np.load(os.path.join(G, "rhs.npz"))
+    seen = set()
+    for k in range(int(rhsg["n_cases"])):
+        for model in ("std", "traps"):
+            a = rhsg[f"{model}{k}_args"]
+            L = int(a[0])
+            tr = list(a[15:18]) if model == "traps" else [0, 0, 1]
+            par = np.array([[a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12],
+                             q_C / (a[13] * eps0), a[14]] + tr])
+            dy = batch.rhs_batch(par, [a[1]], rhsg[f"{model}{k}_y"][None, :], L, model=model)[0]
+            ref = rhsg[f"{model}{k}_dy"]
+            nE = L + 1
+            scale = np.max(np.abs(ref[:-nE])) + 1e-300
+            np.testing.assert_allclose(dy[:-nE], ref[:-nE], rtol=1e-9, atol=1e-12 * scale)
+            np.testing.assert_allclose(dy[-nE:], ref[-nE:], rtol=1e-12, atol=1e-14 * np.max(np.abs(ref[-nE:])))
+            seen.add((model, L))
+    assert ("traps", 512) in seen and ("std", 512) in seen and ("traps", 128) in seen
+
+
+def _run(gold, key, rtol=1e-7, atol=1e-10):
+    from metrotrpl_amd import batch
+    names, meas, solver, model, ini_mode = [str(x) for x in gold[key + "__meta"]]
+    th, nx, hmax, _, _, min_y = gold[key + "__geom"]
+    idx = {n: i for i, n in enumerate(names.split(","))}
+    sig, status, stats = batch.solve_batch(gold[key + "__state"][None, :], idx, gold[key + "__units"],
+                                           gold[key + "__iniPar"][None, :], float(th), int(nx), gold[key + "__tSteps"],
+                                           hmax=float(hmax), meas=meas, model=model, ini_mode=ini_mode, RTOL=rtol,
+                                           ATOL=atol, return_stats=True)
+    assert status[0] == 0, key
+    return sig[0], stats[0]
+
+
+def test_traps_model(gold, conv):
+    """a5: golden traps trace (real trap parameters) and the reference's null-trap
+    equivalence test (Tests/test_metropolis.py:270-326)."""
+    sig, stats = _run(gold, "traps_thick__tight")
+    e_ref, e_conv = _relerr(sig, gold["traps_thick__tight__sig"]), _relerr(sig, conv["traps_thick__conv"])
+    print("traps: vs tight ref %.2e vs converged %.2e steps %d" % (e_ref, e_conv, stats[0]))
+    assert e_conv <= REL_TOL and e_ref <= REL_TOL
+    # null trap parameters == std model
+    from metrotrpl_amd import batch, workloads as W
+    ix, un, s0 = W.indexes(), W.units(), W.initial_state()
+    t = np.linspace(0, 500, 251)
+    std = batch.solve_batch(s0[None, :], ix, un, [W.STAUB_FLUENCES[3]], 2000.0, 128, t)[0]
+    tix = dict(ix, kC=13, Nt=14, tauE=15)
+    tst = np.concatenate([s0, [0.0, 0.0, 1e99]])
+    tun = np.concatenate([un, [((1e7) ** 3) / (1e9), ((1e-7) ** 3), 1]])
+    trp = batch.solve_batch(tst[None, :], tix, tun, [W.STAUB_FLUENCES[3]], 2000.0, 128, t, model="traps")[0]
+    np.testing.assert_allclose(trp, std, rtol=1e-7)
+
+
+def test_nx512(gold):
+    """configs[4]: nx=512 thick film TRPL and thin film TRTS against the reference's tight traces."""
+    for key in ("cfg5_thick_pl__tight", "cfg5_thin_trts__tight"):
+        sig, stats = _run(gold, key)
+        err = _relerr(sig, gold[key + "__sig"])
+        print(f"{key}: rel={err:.2e} steps={stats[0]} rhs={stats[1]} fac={stats[2]}")
+        assert err <= REL_TOL, (key, err)
+
+
+def test_nx_between_128_and_512():
+    """W=2 and W=4 kernels on a grid refinement study: nx=200, 256, 384 converge to the same PL
+    (second-order spatial scheme) and nx=128 agrees between the wave kernel and the team kernel."""
+    from metrotrpl_amd import batch, _lib as L, workloads as W
+    ix, un, s0 = W.indexes(), W.units(), W.initial_state()
+    t = np.linspace(0, 400, 201)
+    out = {}
+    for nx in (128, 200, 256, 384):
+        out[nx] = batch.solve_batch(s0[None, :], ix, un, [W.STAUB_FLUENCES[5]], 2000.0, nx, t)[0]
+    d1 = np.max(np.abs(out[200] / out[384] - 1))
+    d2 = np.max(np.abs(out[256] / out[384] - 1))
+    assert d2 < d1 < 5e-2 and d2 < 2e-3
+    ctx = L.default_context()
+    try:
+        ctx.set_option("kernel_variant", 1)
+        team = batch.solve_batch(s0[None, :], ix, un, [W.STAUB_FLUENCES[5]], 2000.0, 128, t)[0]
+    finally:
+        ctx.set_option("kernel_variant", 0)
+    np.testing.assert_allclose(team, out[128], rtol=2e-7)
+
+
+def test_team_kernel_w1_golden(gold, conv):
+    """The W=1 team kernel on the golden std cases (same gate as the wave kernel)."""
+    from metrotrpl_amd import _lib as L
+    ctx = L.default_context()
+    worst = 0.0
+    try:
+        ctx.set_option("kernel_variant", 1)
+        for key in [str(k) for k in gold["order"]]:
+            if not key.endswith("__tight") or not key.startswith(("cfg1", "cfg2_1", "cfg3", "trts", "rev")):
+                continue
+            sig, stats = _run(gold, key)
+            worst = max(worst, _relerr(sig, conv[key.replace("__tight", "__conv")]))
+    finally:
+        ctx.set_option("kernel_variant", 0)
+    print("team W=1 worst:", worst)
+    assert worst <= REL_TOL
