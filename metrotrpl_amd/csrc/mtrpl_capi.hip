@@ -19,7 +19,7 @@ using namespace mtrpl;
 struct mtrpl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    SolveTuning tune{0.1, 1e-8, 5e-9, 1e-4, 200000, 0.03, 8};
+    SolveTuning tune{0.1, 5e-9, 5e-9, 1e-4, 200000, 0.03, 8};
     std::string err;
     // IRF tables resident on the device (mtrpl_irf_tables_upload)
     double *d_irf_tab = nullptr;

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
         double fac = fmin(10.0, safety * fbest);
         if (h * fac > hmax) fac = hmax / h;
         if (dorder == 0 && fac >= 0.9 && fac < 1.2) {
-            n_equal = order;  // keep h and the factors; test again after the next step
+            n_equal = order - 2;  // keep h and the factors; test again three steps on
             continue;
         }
         order += dorder;

@@ -78,6 +78,12 @@ __device__ inline double dpp0(double v)
     return r.d;
 }
 
+// Nearest-neighbour exchange across the whole wave as a DPP wave shift (2 VALU moves
+// per double instead of a ds_bpermute round trip).  The lane with no neighbour gets
+// 0.0, which -- like the wrapped value of a bpermute -- only ever meets a zero block.
+__device__ inline double from_prev(double v) { return dpp0<0x138>(v); }  // wave_shr:1: lane i <- lane i-1
+__device__ inline double from_next(double v) { return dpp0<0x130>(v); }  // wave_shl:1: lane i <- lane i+1
+
 // Sum over the 64 lanes, result wave-uniform (in SGPRs).  gfx9 DPP ladder:
 // row_shr 1,2,4,8 inside each row of 16, then row_bcast15 / row_bcast31 carry the
 // row totals forward; the grand total lands in lane 63.
@@ -137,6 +143,9 @@ __device__ inline V2 mvec(const M2 &m, const V2 &v) { return V2{m.a * v.x + m.b 
 // zero through every reduction level), so it contributes exactly 0.
 __device__ inline M2 mshf(const M2 &m, int src) { return M2{shf(m.a, src), shf(m.b, src), shf(m.c, src), shf(m.d, src)}; }
 __device__ inline V2 vshf(const V2 &v, int src) { return V2{shf(v.x, src), shf(v.y, src)}; }
+__device__ inline M2 mnext(const M2 &m) { return M2{from_next(m.a), from_next(m.b), from_next(m.c), from_next(m.d)}; }
+__device__ inline V2 vnext(const V2 &v) { return V2{from_next(v.x), from_next(v.y)}; }
+__device__ inline V2 vprev(const V2 &v) { return V2{from_prev(v.x), from_prev(v.y)}; }
 
 // ---- RHS: forward_solver.py:332-372 (dydt_numba) ------------------------------
 // y[r], y[R+r], y[2R+r] = N_i, P_i, E_i (E on the left face of node i), i = lane*R+r.
@@ -145,8 +154,8 @@ template <int R>
 __device__ inline void rhs_std(const Par &p, const double (&y)[3 * R], double (&f)[3 * R], int lane, int L)
 {
     double Jn[R + 1], Jp[R + 1];
-    const double Nl = shf(y[R - 1], (lane + 63) & 63);
-    const double Pl = shf(y[2 * R - 1], (lane + 63) & 63);
+    const double Nl = from_prev(y[R - 1]);
+    const double Pl = from_prev(y[2 * R - 1]);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = lane * R + r;
@@ -165,8 +174,8 @@ __device__ inline void rhs_std(const Par &p, const double (&y)[3 * R], double (&
         Jn[r] = jn;
         Jp[r] = jp;
     }
-    Jn[R] = shf(Jn[0], (lane + 1) & 63);
-    Jp[R] = shf(Jp[0], (lane + 1) & 63);
+    Jn[R] = from_next(Jn[0]);
+    Jp[R] = from_next(Jp[0]);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = lane * R + r;
@@ -222,8 +231,8 @@ __device__ inline void edge_blocks(const Par &p, const double (&y)[3 * R], doubl
 {
     const double cL = c * p.Lam;
     const double dnx = p.DnT * p.idx, dpx = p.DpT * p.idx;
-    const double Nl = shf(y[R - 1], (lane + 63) & 63);
-    const double Pl = shf(y[2 * R - 1], (lane + 63) & 63);
+    const double Nl = from_prev(y[R - 1]);
+    const double Pl = from_prev(y[2 * R - 1]);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = lane * R + r;
@@ -267,8 +276,8 @@ __device__ inline void node_blocks(const Par &p, const double (&y)[3 * R], doubl
 {
     const double cd = c * p.idx;
     // lane 63 wraps to lane 0's edge 0: harmless, its last node is the back surface or padding
-    const M2 LmNext = mshf(Lm[0], (lane + 1) & 63);
-    const M2 RmNext = mshf(Rm[0], (lane + 1) & 63);
+    const M2 LmNext = mnext(Lm[0]);
+    const M2 RmNext = mnext(Rm[0]);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = lane * R + r;
@@ -313,9 +322,9 @@ __device__ inline void build_factors(const Par &p, const double (&yJ)[6], double
     F.put(Factors<2>::BIA_E, lane, mmul(Binv_e, A[0]));
     F.put(Factors<2>::BIC_E, lane, mmul(Binv_e, C[0]));
     const int nx = (lane + 1) & 63;
-    const M2 Binv_up = mshf(Binv_e, nx);
-    const M2 A_up = mshf(A[0], nx);
-    const M2 C_up = mshf(C[0], nx);
+    const M2 Binv_up = mnext(Binv_e);
+    const M2 A_up = mnext(A[0]);
+    const M2 C_up = mnext(C[0]);
     const M2 cr_al = mmul(A[1], Binv_e);
     const M2 cr_ga = mmul(C[1], Binv_up);
     F.put(Factors<2>::CR_AL, lane, cr_al);
@@ -350,7 +359,7 @@ __device__ inline void apply_factors(const Factors<2> &F, const double (&b)[6], 
     V2 wb[3];
     wb[0] = V2{F.w[0][0] * b[4], F.w[0][1] * b[4]};
     wb[1] = V2{F.w[1][0] * b[5], F.w[1][1] * b[5]};
-    wb[2] = vshf(wb[0], lnext);  // lane 63 wraps to edge 0, whose weights are 0
+    wb[2] = vnext(wb[0]);  // lane 63 gets 0: its last node is the back surface or padding
     V2 r[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -358,7 +367,7 @@ __device__ inline void apply_factors(const Factors<2> &F, const double (&b)[6], 
         r[q] = V2{b[q] + F.cd * (nxt.x - wb[q].x), b[2 + q] - F.cd * (nxt.y - wb[q].y)};
     }
     // cyclic reduction of the right-hand side
-    const V2 re_up = vshf(r[0], lnext);
+    const V2 re_up = vnext(r[0]);
     const V2 t1 = mvec(F.get(Factors<2>::CR_AL, lane), r[0]), t2 = mvec(F.get(Factors<2>::CR_GA, lane), re_up);
     V2 rk{r[1].x - t1.x - t2.x, r[1].y - t1.y - t2.y};
 #pragma unroll
@@ -370,7 +379,7 @@ __device__ inline void apply_factors(const Factors<2> &F, const double (&b)[6], 
         rk = V2{rk.x - u1.x - u2.x, rk.y - u1.y - u2.y};
     }
     const V2 xk = mvec(F.Bfin, rk);
-    const V2 xk_prev = vshf(xk, lprev);
+    const V2 xk_prev = vprev(xk);
     const V2 s0 = mvec(F.get(Factors<2>::BINV_E, lane), r[0]), s1 = mvec(F.get(Factors<2>::BIA_E, lane), xk_prev),
              s2 = mvec(F.get(Factors<2>::BIC_E, lane), xk);
     const V2 xe{s0.x - s1.x - s2.x, s0.y - s1.y - s2.y};
