@@ -191,25 +191,84 @@ __global__ void conv_time_kernel(int64_t n_conv, int64_t n_r, double half_dt, do
 // ---------------------------------------------------------------------------
 // Fused likelihood tail, one 256-thread block per (chain, measurement):
 // laplace.py:44-126 + trial_move_evaluation.py:96-158.  The convolved trace is
-// never written to HBM: pass A finds argmax over all n_conv samples chunk by
-// chunk in LDS, pass B recomputes only the (at most 2 per experimental time)
-// samples that the re-interpolation onto the experimental times needs.
+// never written to HBM: pass A finds argmax over all n_conv samples, pass B
+// recomputes only the (at most 2 per experimental time) samples that the
+// re-interpolation onto the experimental times needs.
+//
+// The resampled signal of laplace.py:68-74 is a LINEAR interpolant of the nt
+// simulated samples, so inside one simulation interval the three Simpson moments
+// of laplace.py:198-200 are I2 = 0, I1 = 2*delta*slope, I0 = linear in j, and the
+// 189-tap sum of laplace.py:204-210 over a run of such intervals collapses to
+// differences of three prefix sums of the moment table:
+//   sum_m (a - c1*m) T0[m] + c1*T1[m] = a*dP0 - c1*dQ0 + c1*dP1 .
+// A window of 189 taps crosses 3-4 simulation intervals, so one output costs a
+// few dozen flops instead of 567 FMAs; intervals that straddle a simulation
+// sample (and the snapped last one) are evaluated directly from the definition.
 constexpr int kLikeBlock = 256;
 
-__device__ inline double conv_sample(const double *sig_t, const double *sig_y, int nt, const double *T, int nk,
-                                     int64_t k, int64_t n_r, double half_dt, double t_end)
+struct ConvCtx {
+    const double *st, *sy, *sb;   // LDS: times, values, slopes of the simulation intervals
+    const double *T;              // LDS: moment table [nk][3]
+    const double *P0, *Q0, *P1;   // LDS: prefix sums [nk+1]
+    int nt, nk;
+    int64_t n_r, nkk;
+    double half_dt, t_end, inv_2d;
+};
+
+// interval index interp_linear would use for time v (v inside [st[0], st[nt-1]])
+__device__ inline int conv_segment(const ConvCtx &c, double v)
 {
-    // h[k] straight from the definition (laplace.py:204-210), resampling on the fly
+    int lo = 0, hi = c.nt;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (c.st[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    int idx = lo < 1 ? 1 : lo;
+    if (idx > c.nt - 1) idx = c.nt - 1;
+    return idx - 1;
+}
+
+__device__ inline double conv_interp(const ConvCtx &c, double v)
+{
+    if (!(v >= c.st[0] && v <= c.st[c.nt - 1])) return __builtin_nan("");
+    const int q = conv_segment(c, v);
+    return c.sb[q] * (v - c.st[q]) + c.sy[q];
+}
+
+// h[k] of laplace.py:204-210
+__device__ inline double conv_fast(const ConvCtx &c, int64_t k)
+{
     if (k <= 0) return 0.0;
-    const int64_t lo = (k - nk > 0) ? k - nk : 0;
+    const int64_t lo = (k - c.nk > 0) ? k - c.nk : 0, hi = k - 1;
     double acc = 0.0;
-    double y0 = interp_linear(sig_t, sig_y, nt, resampled_time(2 * lo, n_r, half_dt, t_end));
-    for (int64_t j = lo; j < k; ++j) {
-        const double y1 = interp_linear(sig_t, sig_y, nt, resampled_time(2 * j + 1, n_r, half_dt, t_end));
-        const double y2 = interp_linear(sig_t, sig_y, nt, resampled_time(2 * j + 2, n_r, half_dt, t_end));
-        const double *tt = T + 3 * (k - 1 - j);
-        acc += (y1 * tt[0] + (y2 - y0) * tt[1] + (2 * (y2 - 2 * y1 + y0)) * tt[2]);
-        y0 = y2;
+    int64_t cur = lo;
+    while (cur <= hi) {
+        const double t0 = resampled_time(2 * cur, c.n_r, c.half_dt, c.t_end);
+        const double t1 = resampled_time(2 * cur + 1, c.n_r, c.half_dt, c.t_end);
+        const double t2 = resampled_time(2 * cur + 2, c.n_r, c.half_dt, c.t_end);
+        const int q = conv_segment(c, t1);
+        const bool regular = (t0 >= c.st[q]) && (t2 <= c.st[q + 1]) && (cur < c.nkk - 1);
+        if (regular) {
+            // last interval j of this run: tau_{2j+2} <= st[q+1]
+            int64_t je = (int64_t)floor(c.st[q + 1] * c.inv_2d) - 1;
+            while (resampled_time(2 * je + 4, c.n_r, c.half_dt, c.t_end) <= c.st[q + 1]) ++je;
+            while (resampled_time(2 * je + 2, c.n_r, c.half_dt, c.t_end) > c.st[q + 1]) --je;
+            if (je > c.nkk - 2) je = c.nkk - 2;
+            if (je < cur) je = cur;
+            const int64_t jb = je < hi ? je : hi;
+            const int ma = (int)(k - 1 - jb), mb = (int)(k - 1 - cur);
+            const double c1 = 2.0 * c.half_dt * c.sb[q];
+            const double yc = c.sb[q] * (t1 - c.st[q]) + c.sy[q];  // I0 at j = cur
+            // I0[j] = yc + c1*(j - cur) = (yc + c1*mb) - c1*m
+            acc += (yc + c1 * (double)mb) * (c.P0[mb + 1] - c.P0[ma]) - c1 * (c.Q0[mb + 1] - c.Q0[ma]) +
+                   c1 * (c.P1[mb + 1] - c.P1[ma]);
+            cur = jb + 1;
+        } else {
+            const double y0 = conv_interp(c, t0), y1 = conv_interp(c, t1), y2 = conv_interp(c, t2);
+            const double *tt = c.T + 3 * (k - 1 - cur);
+            acc += (y1 * tt[0] + (y2 - y0) * tt[1] + (2 * (y2 - 2 * y1 + y0)) * tt[2]);
+            ++cur;
+        }
     }
     return acc;
 }
@@ -238,50 +297,49 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
     }
     double *st = smem;            // [nt] simulation times
     double *sy = st + nt;         // [nt] simulated signal
-    double *sol = sy + nt;        // [n_exp] signal at the experimental times
-    double *wk = sol + n_exp;     // IRF work space: T[3nk], I0,I1,I2[kLikeBlock+nk]
+    double *sb = sy + nt;         // [nt] interval slopes (laplace.py:74 via interp1d)
+    double *sol = sb + nt;        // [n_exp] signal at the experimental times; later err^2
+    double *su2 = sol + n_exp;    // [n_exp] 2*unc^2
+    double *wk = su2 + n_exp;     // IRF work space: T[3nk], P0,Q0,P1[nk+1]
     for (int i = tid; i < nt; i += kLikeBlock) { st[i] = tsteps[ds.t_off + i]; sy[i] = sig[ds.sig_off + i]; }
     __syncthreads();
+    for (int i = tid; i < nt - 1; i += kLikeBlock) sb[i] = (sy[i + 1] - sy[i]) / (st[i + 1] - st[i]);
     const double *et = exp_t + ds.exp_off, *ey = exp_y + ds.exp_off, *eu = exp_u + ds.exp_off;
     int n_c = n_exp;  // number of compared samples
     bool failed = false;
     if (ds.irf >= 0) {
         const int nk = set.nk[ds.irf];
         const double *Tg = tables + set.off[ds.irf];
-        const double half_dt = set.dt[ds.irf] / 2, t_end = st[nt - 1];
-        // len(np.arange(0, t_end + dt/4, dt/2)), laplace.py:68
-        const int64_t n_r = (int64_t)ceil((t_end + set.dt[ds.irf] / 4) / half_dt);
-        const int64_t nkk = (n_r - 1) / 2;  // last convolved index
-        double *T = wk, *I0 = T + 3 * nk, *I1 = I0 + (kLikeBlock + nk), *I2 = I1 + (kLikeBlock + nk);
+        double *T = wk, *P0 = T + 3 * nk, *Q0 = P0 + (nk + 1), *P1 = Q0 + (nk + 1);
         for (int i = tid; i < 3 * nk; i += kLikeBlock) T[i] = Tg[i];
+        __syncthreads();
+        if (tid < 3) {  // prefix sums of the moment table (sequential: same rounding every time)
+            double a = 0.0;
+            double *dst = (tid == 0) ? P0 : ((tid == 1) ? Q0 : P1);
+            dst[0] = 0.0;
+            for (int m = 0; m < nk; ++m) {
+                a += (tid == 0) ? T[3 * m] : ((tid == 1) ? (double)m * T[3 * m] : T[3 * m + 1]);
+                dst[m + 1] = a;
+            }
+        }
+        __syncthreads();
+        ConvCtx c;
+        c.st = st; c.sy = sy; c.sb = sb; c.T = T; c.P0 = P0; c.Q0 = Q0; c.P1 = P1;
+        c.nt = nt; c.nk = nk;
+        c.half_dt = set.dt[ds.irf] / 2;
+        c.t_end = st[nt - 1];
+        c.inv_2d = 1.0 / (2.0 * c.half_dt);
+        // len(np.arange(0, t_end + dt/4, dt/2)), laplace.py:68
+        c.n_r = (int64_t)ceil((c.t_end + set.dt[ds.irf] / 4) / c.half_dt);
+        c.nkk = (c.n_r - 1) / 2;  // last convolved index
+        const int64_t nkk = c.nkk, n_r = c.n_r;
+        const double half_dt = c.half_dt, t_end = c.t_end;
         // ---- pass A: argmax of the convolved trace (laplace.py:82) ----
         double best = 0.0;
         int64_t bi = nkk + 1;
-        for (int64_t k0 = 0; k0 <= nkk; k0 += kLikeBlock) {
-            const int64_t jbase = k0 - nk;
-            __syncthreads();
-            for (int i = tid; i < kLikeBlock + nk; i += kLikeBlock) {
-                const int64_t j = jbase + i;
-                double a = 0.0, b = 0.0, c = 0.0;
-                if (j >= 0 && j < nkk) {
-                    const double y0 = interp_linear(st, sy, nt, resampled_time(2 * j, n_r, half_dt, t_end));
-                    const double y1 = interp_linear(st, sy, nt, resampled_time(2 * j + 1, n_r, half_dt, t_end));
-                    const double y2 = interp_linear(st, sy, nt, resampled_time(2 * j + 2, n_r, half_dt, t_end));
-                    c = 2 * (y2 - 2 * y1 + y0); b = (y2 - y0); a = y1;
-                }
-                I0[i] = a; I1[i] = b; I2[i] = c;
-            }
-            __syncthreads();
-            const int64_t k = k0 + tid;
-            if (k <= nkk) {
-                double acc = 0.0;
-                const int64_t taps = (k < nk) ? k : nk;
-                for (int64_t m = taps - 1; m >= 0; --m) {
-                    const int li = (int)(k - 1 - m - jbase);
-                    acc += (I0[li] * T[3 * m] + I1[li] * T[3 * m + 1] + I2[li] * T[3 * m + 2]);
-                }
-                if (argmax_better(acc, k, best, bi, nkk + 1)) { best = acc; bi = k; }
-            }
+        for (int64_t k = tid; k <= nkk; k += kLikeBlock) {
+            const double acc = conv_fast(c, k);
+            if (argmax_better(acc, k, best, bi, nkk + 1)) { best = acc; bi = k; }
         }
         block_argmax(best, bi, nkk + 1, red_v, red_i);
         const double t_shift = resampled_time(2 * bi, n_r, half_dt, t_end);
@@ -315,8 +373,7 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
                 if (idx > nkk) idx = nkk;
                 const double x0 = resampled_time(2 * (idx - 1), n_r, half_dt, t_end) - t_shift;
                 const double x1 = resampled_time(2 * idx, n_r, half_dt, t_end) - t_shift;
-                const double h0 = conv_sample(st, sy, nt, T, nk, idx - 1, n_r, half_dt, t_end);
-                const double h1 = conv_sample(st, sy, nt, T, nk, idx, n_r, half_dt, t_end);
+                const double h0 = conv_fast(c, idx - 1), h1 = conv_fast(c, idx);
                 const double slope = (h1 - h0) / (x1 - x0);
                 v = slope * (te - x0) + h0;
             }
@@ -335,30 +392,40 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
     atomicAdd(&s_cnt[1], neg);
     __syncthreads();
     if (!((double)s_cnt[1] < neg_frac_tol * (double)n_c)) failed = true;
-    // ---- :147-156: err_sq and ll(T) ----
-    double e2[4], u2[4];  // n_exp <= 4*kLikeBlock checked by the host
-    int cntp = 0;
+    // ---- :147-156: err_sq and ll(T) = -sum err_sq / (sigma^2 T + 2 u^2) ----
     for (int i = tid; i < n_c; i += kLikeBlock) {
         double s = sol[i];
         if (s < 0) s *= -1;
         const double e = (log10(s) + ds.scale_shift - ey[i]);
-        e2[cntp] = e * e;
-        u2[cntp] = 2 * (eu[i] * eu[i]);
-        cntp++;
+        sol[i] = e * e;
+        su2[i] = 2 * (eu[i] * eu[i]);
     }
+    __syncthreads();
     const double sg2 = ds.sigma * ds.sigma;
-    for (int j = 0; j < nT; ++j) {
-        const double Tj = temps[j];
-        double part = 0.0;
-        for (int q = 0; q < cntp; ++q) part += e2[q] / (sg2 * Tj + u2[q]);
-        part = wave_sum(part);
-        __syncthreads();
-        if ((tid & 63) == 0) red_v[tid >> 6] = part;
-        __syncthreads();
-        if (tid == 0) {
-            double tot = -(red_v[0] + red_v[1] + red_v[2] + red_v[3]);
+    if (nT >= 32) {
+        // many ladder temperatures: one thread per temperature walks the n_c points
+        for (int j = tid; j < nT; j += kLikeBlock) {
+            const double sT = sg2 * temps[j];
+            double tot = 0.0;
+            for (int i = 0; i < n_c; ++i) tot += sol[i] / (sT + su2[i]);
+            tot = -tot;
             if (failed || tot != tot) tot = -__builtin_inf();  // :70-72,:159-165
             ll[sidx * nT + j] = tot;
+        }
+    } else {
+        for (int j = 0; j < nT; ++j) {
+            const double sT = sg2 * temps[j];
+            double part = 0.0;
+            for (int i = tid; i < n_c; i += kLikeBlock) part += sol[i] / (sT + su2[i]);
+            part = wave_sum(part);
+            __syncthreads();
+            if ((tid & 63) == 0) red_v[tid >> 6] = part;
+            __syncthreads();
+            if (tid == 0) {
+                double tot = -(red_v[0] + red_v[1] + red_v[2] + red_v[3]);
+                if (failed || tot != tot) tot = -__builtin_inf();
+                ll[sidx * nT + j] = tot;
+            }
         }
     }
 }

@@ -86,6 +86,12 @@ def test_loglik_batch_of_chains_and_failures():
         one = eng.eval(states[c:c + 1], TEMPS)[0]
         np.testing.assert_array_equal(one, t_all[c])
         assert np.all(np.isfinite(one))
+        if c == 2:
+            # constant (clamped) signal: the convolved trace is a plateau of mathematically equal
+            # samples, so np.argmax -- and with it the time shift -- is decided by summation
+            # round-off (numpy's pairwise sums, the oracle's sequential sums and the kernel's
+            # prefix sums all differ); only finiteness is meaningful here
+            continue
         _, ref = O.eval_trial_move(states[c], dict(uniq, _T=1.0), tight, temperatures=TEMPS)
         np.testing.assert_allclose(t_all[c], ref, rtol=1e-6)
     # ll(T) is increasing in T (denominator grows), and ll(T) != ll(1)/T because uncs > 0
@@ -117,3 +123,30 @@ def test_loglik_batch_of_chains_and_failures():
     assert np.all(np.isneginf(ll[2, 1])) and np.all(np.isfinite(ll[2, 0]))
     ref = O.loglik_tail(good[0], shared["_vals"][0], shared["_uncs"][0], 0.0, 1.0, TEMPS)
     np.testing.assert_allclose(ll[1, 0], ref, rtol=1e-12)
+
+
+@pytest.mark.parametrize("kind", ["power", "jitter", "coarse"])
+def test_loglik_irf_on_unaligned_time_grids(kind):
+    """The prefix-sum form of the FIR must agree with the definition when the simulation
+    samples do NOT fall on the IRF half-step grid (intervals straddling a sample are
+    evaluated directly) and when the grid is non-uniform."""
+    from oracle import oracle as O
+    ev, state, uniq, shared = _setup("irf")
+    rng = np.random.default_rng(5)
+    if kind == "power":
+        t = 100.0 * np.linspace(0, 1, 701) ** 1.3
+    elif kind == "jitter":
+        t = np.linspace(0, 100, 1001)
+        t[1:-1] += rng.uniform(-0.03, 0.03, 999)
+    else:
+        t = np.linspace(0, 60.0, 41)  # 1.5 ns steps: not a multiple of 0.025/2 * 2
+        t[1:] += 0.00371
+    n = len(t)
+    shared = dict(shared, _times=[t, t], _vals=[23 - np.linspace(0, 1, n), 24 - np.linspace(0, 2, n)],
+                  _uncs=[np.full(n, 0.02), np.full(n, 0.02)])
+    eng = _engine(state, uniq, shared)
+    table = eng.eval(np.asarray(state)[None, :], TEMPS)[0]
+    tight = dict(shared, rtol=1e-10, atol=1e-14)
+    _, ref = O.eval_trial_move(state, dict(uniq, _T=1.0), tight, temperatures=TEMPS)
+    assert np.all(np.isfinite(ref))
+    np.testing.assert_allclose(table, ref, rtol=1e-6)
