@@ -12,7 +12,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "lib", "libmetrotrpl_amd.so")
+LIB_PATH = os.environ.get("MTRPL_LIB_PATH") or os.path.join(_PKG, "lib", "libmetrotrpl_amd.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 OK, ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NO_DEVICE = 0, 1, 2, 3, 4

@@ -5,6 +5,18 @@
 #pragma once
 #include "solver_device.hpp"
 
+// Diagnostic build only (-DMTRPL_STAMPS): s_memtime per phase; the real kernel has no stamps.
+#ifdef MTRPL_STAMPS
+#define MTRPL_STAMP(acc)                                        \
+    do {                                                        \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        acc += now_ - tlast_;                                   \
+        tlast_ = now_;                                          \
+    } while (0)
+#else
+#define MTRPL_STAMP(acc) do { } while (0)
+#endif
+
 namespace mtrpl {
 
 struct SolveTuning {
@@ -68,6 +80,73 @@ __device__ inline void change_D(double (&D)[8][V], int order, double factor, int
 #pragma unroll
             for (int v = 0; v < V; ++v) D[ii][v] = Dn[ii][v];
         }
+}
+
+// ---- order-specialised pieces of the NDF step -----------------------------------
+// `order` is wave-uniform, so a scalar switch picks one of five fully static
+// bodies: no per-row predication, and every D[k][v] has a fixed register.
+#define MTRPL_ORDER_SWITCH(order_, CALL)      \
+    switch (order_) {                          \
+        case 1: { constexpr int K = 1; CALL; } break; \
+        case 2: { constexpr int K = 2; CALL; } break; \
+        case 3: { constexpr int K = 3; CALL; } break; \
+        case 4: { constexpr int K = 4; CALL; } break; \
+        default: { constexpr int K = 5; CALL; } break; \
+    }
+
+template <int K, int V>
+__device__ inline void ndf_predict(const double (&D)[8][V], double (&yp)[V], double (&psi)[V])
+{
+    constexpr double g[6] = {0.0, 1.0, 1.5, 1.5 + 1.0 / 3.0, 1.5 + 1.0 / 3.0 + 0.25, 1.5 + 1.0 / 3.0 + 0.25 + 0.2};
+#pragma unroll
+    for (int v = 0; v < V; ++v) { yp[v] = D[0][v]; psi[v] = 0.0; }
+#pragma unroll
+    for (int j = 1; j <= K; ++j)
+#pragma unroll
+        for (int v = 0; v < V; ++v) { yp[v] += D[j][v]; psi[v] += g[j] * D[j][v]; }
+}
+
+// D[K+2] = d - D[K+1]; D[K+1] = d; D[i] += D[i+1], i = K..0
+template <int K, int V>
+__device__ inline void ndf_update(double (&D)[8][V], const double (&d)[V])
+{
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        D[K + 2][v] = d[v] - D[K + 1][v];
+        D[K + 1][v] = d[v];
+    }
+#pragma unroll
+    for (int i = K; i >= 0; --i)
+#pragma unroll
+        for (int v = 0; v < V; ++v) D[i][v] += D[i + 1][v];
+}
+
+// value of the order-K interpolating polynomial at tq (t = end of the step just taken)
+template <int K, int V>
+__device__ inline void ndf_dense(const double (&D)[8][V], double tq, double t, double h, double ih, double (&yq)[V])
+{
+#pragma unroll
+    for (int v = 0; v < V; ++v) yq[v] = D[0][v];
+    double pj = 1.0;
+#pragma unroll
+    for (int j = 1; j <= K; ++j) {
+        pj *= (tq - (t - (double)(j - 1) * h)) * ih * (1.0 / (double)j);
+#pragma unroll
+        for (int v = 0; v < V; ++v) yq[v] += D[j][v] * pj;
+    }
+}
+
+// squared weighted norms of D[K] (order-1 candidate) and D[K+2] (order+1 candidate)
+template <int K, int V>
+__device__ inline void ndf_sel(const double (&D)[8][V], const double (&isc)[V], double &sm, double &sp)
+{
+    sm = 0.0;
+    sp = 0.0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        sm += (D[K][v] * isc[v]) * (D[K][v] * isc[v]);
+        sp += (D[K + 2][v] * isc[v]) * (D[K + 2][v] * isc[v]);
+    }
 }
 
 // signal of one state: dx * sum_i ks (N_i P_i - n0 p0)  (forward_solver.py:228-236,:258-269)
@@ -228,7 +307,12 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
     int io = 1;
     const double t_end = (nt > 1) ? ts[nt - 1] : 0.0;
 
+#ifdef MTRPL_STAMPS
+    unsigned long long tlast_ = __builtin_amdgcn_s_memtime(), ph_sel = 0, ph_pred = 0, ph_fac = 0, ph_newt = 0,
+                       ph_err = 0, ph_upd = 0, ph_dense = 0;
+#endif
     while (io < nt) {
+        MTRPL_STAMP(ph_sel);
         if (n_steps >= tune.max_steps) { st = MTRPL_SOLVE_STOPPED_EARLY; break; }
         bool jac_current = (n_steps == 0);
         bool accepted = false;
@@ -238,16 +322,9 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
         while (!accepted) {
             if (++attempts > 60 || !(h > 1e-13 * fmax(t, 1e-3))) { st = MTRPL_SOLVE_STOPPED_EARLY; break; }
             // predictor
+            MTRPL_STAMP(ph_err);
             double yp[V], psi[V];
-#pragma unroll
-            for (int v = 0; v < V; ++v) { yp[v] = D[0][v]; psi[v] = 0.0; }
-#pragma unroll
-            for (int j = 1; j <= 5; ++j)
-                if (j <= order) {
-                    const double gj = ndf_gamma(j);
-#pragma unroll
-                    for (int v = 0; v < V; ++v) { yp[v] += D[j][v]; psi[v] += gj * D[j][v]; }
-                }
+            MTRPL_ORDER_SWITCH(order, (ndf_predict<K, V>(D, yp, psi)))
             const double ialpha = frcp(ndf_alpha(order));
             const double c = h * ialpha;
 #pragma unroll
@@ -256,15 +333,18 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
                 isc[v] = frcp(atol + rtol * fabs(yp[v]));
             }
             // simplified Newton
+            MTRPL_STAMP(ph_pred);
             bool converged = false;
             int n_iter = 0;
             while (!converged) {
                 if (!have_fac) {
+                    MTRPL_STAMP(ph_newt);
                     build_factors(p, yJ, c, lane, L, F);
                     have_fac = true;
                     n_fac++;
                     rate_prev = 1.0;  // new matrix: measure the rate afresh
                     rate_age = 0;
+                    MTRPL_STAMP(ph_fac);
                 }
 #pragma unroll
                 for (int v = 0; v < V; ++v) { d[v] = 0.0; yn[v] = yp[v]; }
@@ -317,7 +397,9 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
                 have_fac = false;
                 continue;
             }
-            safety = 0.9 * (2.0 * 4 + 1) / (2.0 * 4 + n_iter);
+            MTRPL_STAMP(ph_newt);
+            // 0.9 * (2*4 + 1) / (2*4 + n_iter), n_iter = 1..4
+            safety = (n_iter == 1) ? 0.9 : ((n_iter == 2) ? 0.81 : ((n_iter == 3) ? 8.1 / 11.0 : 0.675));
             const double ec = ndf_errc(order);
 #pragma unroll
             for (int v = 0; v < V; ++v) w[v] = ec * d[v] * isc[v];
@@ -334,69 +416,28 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
             }
         }
         if (!accepted) break;
+        MTRPL_STAMP(ph_err);
         n_steps++;
         n_equal++;
         t += h;
         // update differences: D[order+2] = d - D[order+1]; D[order+1] = d; D[i] += D[i+1]
-#pragma unroll
-        for (int k = 2; k < 8; ++k)
-            if (k == order + 2) {
-#pragma unroll
-                for (int v = 0; v < V; ++v) D[k][v] = d[v] - D[k - 1][v];
-            }
-#pragma unroll
-        for (int k = 1; k < 7; ++k)
-            if (k == order + 1) {
-#pragma unroll
-                for (int v = 0; v < V; ++v) D[k][v] = d[v];
-            }
-#pragma unroll
-        for (int i = 5; i >= 0; --i)
-            if (i <= order) {
-#pragma unroll
-                for (int v = 0; v < V; ++v) D[i][v] += D[i + 1][v];
-            }
+        MTRPL_ORDER_SWITCH(order, (ndf_update<K, V>(D, d)))
         // dense output (polynomial through the last order+1 steps), forward_solver.py:167
+        MTRPL_STAMP(ph_upd);
         const double ih = frcp(h);
         while (io < nt) {
             const double tq = ts[io];
             if (tq > t * (1.0 + 1e-15)) break;
             double yq[V];
-#pragma unroll
-            for (int v = 0; v < V; ++v) yq[v] = D[0][v];
-            double pj = 1.0;
-#pragma unroll
-            for (int j = 1; j <= 5; ++j)
-                if (j <= order) {
-                    pj *= (tq - (t - (double)(j - 1) * h)) * ih * (1.0 / (double)j);
-#pragma unroll
-                    for (int v = 0; v < V; ++v) yq[v] += D[j][v] * pj;
-                }
+            MTRPL_ORDER_SWITCH(order, (ndf_dense<K, V>(D, tq, t, h, ih, yq)))
             emit(io, signal_of<R>(p, yq, meas, lane, L, sig_scale));
             io++;
         }
+        MTRPL_STAMP(ph_dense);
         if (n_equal < order + 1) continue;
         // order / step-size selection
-        double sel_m[V], sel_p[V];
-#pragma unroll
-        for (int v = 0; v < V; ++v) { sel_m[v] = 0.0; sel_p[v] = 0.0; }
-#pragma unroll
-        for (int k = 1; k < 8; ++k) {
-            if (k == order) {
-#pragma unroll
-                for (int v = 0; v < V; ++v) sel_m[v] = D[k][v];
-            }
-            if (k == order + 2) {
-#pragma unroll
-                for (int v = 0; v < V; ++v) sel_p[v] = D[k][v];
-            }
-        }
         double sm = 0.0, sp = 0.0;
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-            sm += (sel_m[v] * isc[v]) * (sel_m[v] * isc[v]);
-            sp += (sel_p[v] * isc[v]) * (sel_p[v] * isc[v]);
-        }
+        MTRPL_ORDER_SWITCH(order, (ndf_sel<K, V>(D, isc, sm, sp)))
         const double em = (order > 1) ? ndf_errc(order - 1) * uniform(sqrt(wave_sum(sm) * inv_S)) : 1e300;
         const double ep = (order < 5) ? ndf_errc(order + 1) * uniform(sqrt(wave_sum(sp) * inv_S)) : 1e300;
         const double fm = (order > 1) ? inv_root(em, order) : 0.0;
@@ -434,6 +475,11 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
             int32_t *s = stats + 8 * sidx;
             s[0] = n_steps; s[1] = n_rhs; s[2] = n_fac; s[3] = n_jac;
             s[4] = n_rej; s[5] = n_nfail; s[6] = order; s[7] = 0;
+#ifdef MTRPL_STAMPS
+            s[1] = (int)(ph_sel >> 10); s[2] = (int)(ph_pred >> 10); s[3] = (int)(ph_fac >> 10);
+            s[4] = (int)(ph_newt >> 10); s[5] = (int)(ph_err >> 10); s[6] = (int)(ph_upd >> 10);
+            s[7] = (int)(ph_dense >> 10);
+#endif
         }
     }
 }

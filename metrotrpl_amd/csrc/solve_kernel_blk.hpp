@@ -203,15 +203,7 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
             if (++attempts > 60 || !(h > 1e-13 * fmax(t, 1e-3))) { st = MTRPL_SOLVE_STOPPED_EARLY; break; }
             // predictor
             double yp[V], psi[V];
-#pragma unroll
-            for (int v = 0; v < V; ++v) { yp[v] = D[0][v]; psi[v] = 0.0; }
-#pragma unroll
-            for (int j = 1; j <= 5; ++j)
-                if (j <= order) {
-                    const double gj = ndf_gamma(j);
-#pragma unroll
-                    for (int v = 0; v < V; ++v) { yp[v] += D[j][v]; psi[v] += gj * D[j][v]; }
-                }
+            MTRPL_ORDER_SWITCH(order, (ndf_predict<K, V>(D, yp, psi)))
             const double ialpha = frcp(ndf_alpha(order));
             const double c = h * ialpha;
 #pragma unroll
@@ -302,65 +294,21 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
         n_equal++;
         t += h;
         // update differences: D[order+2] = d - D[order+1]; D[order+1] = d; D[i] += D[i+1]
-#pragma unroll
-        for (int k = 2; k < 8; ++k)
-            if (k == order + 2) {
-#pragma unroll
-                for (int v = 0; v < V; ++v) D[k][v] = d[v] - D[k - 1][v];
-            }
-#pragma unroll
-        for (int k = 1; k < 7; ++k)
-            if (k == order + 1) {
-#pragma unroll
-                for (int v = 0; v < V; ++v) D[k][v] = d[v];
-            }
-#pragma unroll
-        for (int i = 5; i >= 0; --i)
-            if (i <= order) {
-#pragma unroll
-                for (int v = 0; v < V; ++v) D[i][v] += D[i + 1][v];
-            }
+        MTRPL_ORDER_SWITCH(order, (ndf_update<K, V>(D, d)))
         // dense output (polynomial through the last order+1 steps), forward_solver.py:167
         const double ih = frcp(h);
         while (io < nt) {
             const double tq = ts[io];
             if (tq > t * (1.0 + 1e-15)) break;
             double yq[V];
-#pragma unroll
-            for (int v = 0; v < V; ++v) yq[v] = D[0][v];
-            double pj = 1.0;
-#pragma unroll
-            for (int j = 1; j <= 5; ++j)
-                if (j <= order) {
-                    pj *= (tq - (t - (double)(j - 1) * h)) * ih * (1.0 / (double)j);
-#pragma unroll
-                    for (int v = 0; v < V; ++v) yq[v] += D[j][v] * pj;
-                }
+            MTRPL_ORDER_SWITCH(order, (ndf_dense<K, V>(D, tq, t, h, ih, yq)))
             emit(io, sigof(yq));
             io++;
         }
         if (n_equal < order + 1) continue;
         // order / step-size selection
-        double sel_m[V], sel_p[V];
-#pragma unroll
-        for (int v = 0; v < V; ++v) { sel_m[v] = 0.0; sel_p[v] = 0.0; }
-#pragma unroll
-        for (int k = 1; k < 8; ++k) {
-            if (k == order) {
-#pragma unroll
-                for (int v = 0; v < V; ++v) sel_m[v] = D[k][v];
-            }
-            if (k == order + 2) {
-#pragma unroll
-                for (int v = 0; v < V; ++v) sel_p[v] = D[k][v];
-            }
-        }
         double sm = 0.0, sp = 0.0;
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-            sm += (sel_m[v] * isc[v]) * (sel_m[v] * isc[v]);
-            sp += (sel_p[v] * isc[v]) * (sel_p[v] * isc[v]);
-        }
+        MTRPL_ORDER_SWITCH(order, (ndf_sel<K, V>(D, isc, sm, sp)))
         team_sum2<W>(tm, sm, sp);
         const double em = (order > 1) ? ndf_errc(order - 1) * sqrt(sm * inv_S) : 1e300;
         const double ep = (order < 5) ? ndf_errc(order + 1) * sqrt(sp * inv_S) : 1e300;

@@ -1,0 +1,102 @@
+"""GPU edge cases through the C ABI: empty and ragged batches, tiny grids, a single
+sample time, mixed measurement types and grid sizes in one launch, integrator give-up."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx():
+    from metrotrpl_amd import _lib as L
+    return L, L.default_context()
+
+
+def test_empty_batch_is_a_noop():
+    L, ctx = _ctx()
+    assert L.lib().mtrpl_solve_batch(ctx.handle, 0, None, None, 0, None, 0, None, 0, None, None) == 0
+    assert L.lib().mtrpl_rhs_batch(ctx.handle, 0, 16, 0, None, None, None, None) == 0
+
+
+def test_ragged_batch_matches_individual_calls():
+    """Solves with different nx, thickness, nt, time grids, meas types and ini modes in ONE launch."""
+    from metrotrpl_amd import batch, workloads as W
+    L, ctx = _ctx()
+    ix, un, s0 = W.indexes(), W.units(), W.initial_state()
+    grids = [np.linspace(0, 50, 26), np.linspace(0, 300, 301), np.array([0.0]), np.linspace(0, 10, 5) ** 2 / 10,
+             np.linspace(0, 120, 61)]
+    nxs = [16, 128, 64, 3, 100]
+    meas = ["TRPL", "TRTS", "TRPL", "TRPL", "TRTS"]
+    thick = [311.0, 2000.0, 500.0, 100.0, 311.0]
+    singles = []
+    for k in range(5):
+        ini = [[1.92e12, 6e4, 1]] if k != 2 else [np.full(nxs[k], 1e15)]
+        singles.append(batch.solve_batch(s0[None, :], ix, un, ini, thick[k], nxs[k], grids[k], meas=meas[k],
+                                         ini_mode="fluence" if k != 2 else "density")[0])
+    # pack all five into one descriptor array by hand
+    par = batch.pack_params((s0 * un)[None, :], ix)
+    d = np.zeros(5, dtype=L.SOLVE_DESC_DTYPE)
+    t_all = np.concatenate(grids)
+    t_off = np.concatenate([[0], np.cumsum([len(g) for g in grids])[:-1]])
+    ini = np.full(64, 1e15)
+    for k in range(5):
+        d[k]["par"] = par[0]
+        d[k]["thickness"], d[k]["hmax"], d[k]["rtol"], d[k]["atol"] = thick[k], 4.0, 1e-7, 1e-10
+        d[k]["min_y"] = np.finfo(float).tiny
+        d[k]["ini"] = [1.92e12, 6e4, 1]
+        d[k]["nx"], d[k]["nt"], d[k]["meas"] = nxs[k], len(grids[k]), L.MEAS[meas[k]]
+        d[k]["model"], d[k]["ini_mode"] = 0, 1 if k != 2 else 0
+        d[k]["ini_off"], d[k]["t_off"], d[k]["out_off"] = 0, t_off[k], t_off[k]
+    out = np.empty(len(t_all))
+    status = np.zeros(5, dtype=np.int32)
+    ctx.check(L.lib().mtrpl_solve_batch(ctx.handle, 5, d.ctypes.data_as(C.c_void_p), L.dptr(ini), 64, L.dptr(t_all),
+                                        len(t_all), L.dptr(out), len(out), L.iptr(status), None))
+    assert np.all(status == 0)
+    for k in range(5):
+        np.testing.assert_array_equal(out[t_off[k]:t_off[k] + len(grids[k])], singles[k])
+    assert len(singles[2]) == 1 and singles[2][0] > 0  # nt = 1: just the t=0 sample
+
+
+def test_descriptor_validation_errors():
+    from metrotrpl_amd import batch, workloads as W
+    ix, un, s0 = W.indexes(), W.units(), W.initial_state()
+    with pytest.raises(ValueError, match="times must start at t=0"):
+        batch.solve_batch(s0[None, :], ix, un, [[1e12, 6e4, 1]], 311.0, 16, np.linspace(1, 10, 5))
+    with pytest.raises(NotImplementedError):
+        batch.solve_batch(s0[None, :], ix, un, [[1e12, 6e4, 1]], 311.0, 1024, np.linspace(0, 10, 5))
+    with pytest.raises(ValueError):
+        batch.solve_batch(s0[None, :], ix, un, [[1e12, 6e4, 1]], -5.0, 16, np.linspace(0, 10, 5))
+
+
+def test_integrator_give_up_zero_fills_like_the_reference():
+    """forward_solver.py:168 + :190-192: samples after the last solved time come from a zeroed
+    state; with max_steps exhausted the status says so."""
+    from metrotrpl_amd import batch, workloads as W
+    L, ctx = _ctx()
+    ix, un, s0 = W.indexes(), W.units(), W.initial_state()
+    t = np.linspace(0, 2000, 101)
+    try:
+        ctx.set_option("max_steps", 40)
+        sig, status, stats = batch.solve_batch(s0[None, :], ix, un, [[1.92e12, 6e4, 1]], 311.0, 64, t, return_stats=True)
+    finally:
+        ctx.set_option("max_steps", 200000)
+    assert status[0] == 1 and stats[0, 0] == 40
+    full = batch.solve_batch(s0[None, :], ix, un, [[1.92e12, 6e4, 1]], 311.0, 64, t)[0]
+    k = int(np.argmax(sig[0] != full))  # first sample that differs = first unsolved time
+    assert k > 0
+    np.testing.assert_array_equal(sig[0, :k], full[:k])
+    # zeroed state -> PL = -ks n0 p0 L 1e23 < min_y -> clamped to min_y (float_info.min) from there on
+    assert np.all(sig[0, k:] == np.finfo(float).tiny)
+
+
+def test_units_none_and_list_state():
+    """solve() with units=None and a python list for `state` (Tests/test_eval_trial_move.py:65,77)."""
+    from metrotrpl_amd.forward_solver import solve
+    from metrotrpl_amd.sim_utils import Grid
+    from metrotrpl_amd import workloads as W
+    ix, un, s0 = W.indexes(), W.units(), W.initial_state()
+    g = Grid(311, 32, np.linspace(0, 20, 11), 4)
+    a = solve([1.92e12, 6e4, 1], g, list(s0 * un), ix, ini_mode="fluence")
+    b = solve([1.92e12, 6e4, 1], g, s0, ix, units=un, ini_mode="fluence")
+    np.testing.assert_array_equal(a, b)
