@@ -156,7 +156,7 @@ typedef struct mtrpl_like_desc {
     int32_t nt;
     int32_t n_exp;
     int32_t irf;       /* index of the IRF table to apply, -1 = none */
-    int32_t reserved;
+    int32_t force_min_y; /* utils.set_min_y (utils.py:16-31, trial_move_evaluation.py:136-140) */
     double scale_shift; /* log10(scale factor), trial_move_evaluation.py:58 */
     double sigma;       /* model_uncertainty[meas_type] */
 } mtrpl_like_desc;

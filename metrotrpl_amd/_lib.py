@@ -38,7 +38,7 @@ class SolveDesc(C.Structure):
 class LikeDesc(C.Structure):
     """mtrpl_like_desc"""
     _fields_ = [("sig_off", C.c_int64), ("t_off", C.c_int64), ("exp_off", C.c_int64),
-                ("nt", C.c_int32), ("n_exp", C.c_int32), ("irf", C.c_int32), ("reserved", C.c_int32),
+                ("nt", C.c_int32), ("n_exp", C.c_int32), ("irf", C.c_int32), ("force_min_y", C.c_int32),
                 ("scale_shift", C.c_double), ("sigma", C.c_double)]
 
 
@@ -48,7 +48,7 @@ SOLVE_DESC_DTYPE = np.dtype([("par", "f8", 16), ("thickness", "f8"), ("hmax", "f
                              ("reserved", "i4"), ("ini_off", "i8"), ("t_off", "i8"), ("out_off", "i8")],
                             align=True)
 LIKE_DESC_DTYPE = np.dtype([("sig_off", "i8"), ("t_off", "i8"), ("exp_off", "i8"), ("nt", "i4"),
-                            ("n_exp", "i4"), ("irf", "i4"), ("reserved", "i4"), ("scale_shift", "f8"),
+                            ("n_exp", "i4"), ("irf", "i4"), ("force_min_y", "i4"), ("scale_shift", "f8"),
                             ("sigma", "f8")], align=True)
 assert SOLVE_DESC_DTYPE.itemsize == C.sizeof(SolveDesc)
 assert LIKE_DESC_DTYPE.itemsize == C.sizeof(LikeDesc)

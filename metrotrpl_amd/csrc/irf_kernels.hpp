@@ -392,10 +392,37 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
     atomicAdd(&s_cnt[1], neg);
     __syncthreads();
     if (!((double)s_cnt[1] < neg_frac_tol * (double)n_c)) failed = true;
+    for (int i = tid; i < n_c; i += kLikeBlock)
+        if (sol[i] < 0) sol[i] *= -1;  // :130
+    if (ds.force_min_y) {
+        // utils.py:16-31 (set_min_y): min_y = 10 ** min(vals - scale_shift);
+        // i_final = np.searchsorted(-sol, -min_y); sol[i_final:] = min_y
+        double vmin = __builtin_inf();
+        for (int i = tid; i < n_c; i += kLikeBlock) vmin = fmin(vmin, ey[i] - ds.scale_shift);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmin = fmin(vmin, __shfl_xor(vmin, o, 64));
+        __syncthreads();
+        if ((tid & 63) == 0) red_v[tid >> 6] = vmin;
+        __syncthreads();
+        const double min_y = pow(10.0, fmin(fmin(red_v[0], red_v[1]), fmin(red_v[2], red_v[3])));
+        if (tid == 0) {
+            int lo = 0, hi = n_c;  // lower_bound of -min_y in -sol, exactly numpy's bisection
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (-sol[mid] < -min_y) lo = mid + 1; else hi = mid;
+            }
+            s_cnt[0] = lo;
+        }
+        __syncthreads();
+        const int i_final = s_cnt[0];
+        __syncthreads();
+        for (int i = tid; i < n_c; i += kLikeBlock)
+            if (i >= i_final) sol[i] = min_y;
+        __syncthreads();
+    }
     // ---- :147-156: err_sq and ll(T) = -sum err_sq / (sigma^2 T + 2 u^2) ----
     for (int i = tid; i < n_c; i += kLikeBlock) {
-        double s = sol[i];
-        if (s < 0) s *= -1;
+        const double s = sol[i];
         const double e = (log10(s) + ds.scale_shift - ey[i]);
         sol[i] = e * e;
         su2[i] = 2 * (eu[i] * eu[i]);

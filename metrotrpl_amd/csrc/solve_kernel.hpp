@@ -306,6 +306,7 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
     int rate_age = 0;
     int io = 1;
     const double t_end = (nt > 1) ? ts[nt - 1] : 0.0;
+    double tq_next = (nt > 1) ? ts[1] : 1e300;
 
 #ifdef MTRPL_STAMPS
     unsigned long long tlast_ = __builtin_amdgcn_s_memtime(), ph_sel = 0, ph_pred = 0, ph_fac = 0, ph_newt = 0,
@@ -426,12 +427,13 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
         MTRPL_STAMP(ph_upd);
         const double ih = frcp(h);
         while (io < nt) {
-            const double tq = ts[io];
+            const double tq = tq_next;  // = ts[io], loaded one output ahead (its latency hides behind a step)
             if (tq > t * (1.0 + 1e-15)) break;
             double yq[V];
             MTRPL_ORDER_SWITCH(order, (ndf_dense<K, V>(D, tq, t, h, ih, yq)))
             emit(io, signal_of<R>(p, yq, meas, lane, L, sig_scale));
             io++;
+            tq_next = (io < nt) ? ts[io] : 1e300;
         }
         MTRPL_STAMP(ph_dense);
         if (n_equal < order + 1) continue;

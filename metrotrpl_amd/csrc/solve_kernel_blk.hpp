@@ -191,6 +191,7 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
     int rate_age = 0;
     int io = 1;
     const double t_end = (nt > 1) ? ts[nt - 1] : 0.0;
+    double tq_next = (nt > 1) ? ts[1] : 1e300;
 
     while (io < nt) {
         if (n_steps >= tune.max_steps) { st = MTRPL_SOLVE_STOPPED_EARLY; break; }
@@ -298,12 +299,13 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
         // dense output (polynomial through the last order+1 steps), forward_solver.py:167
         const double ih = frcp(h);
         while (io < nt) {
-            const double tq = ts[io];
+            const double tq = tq_next;  // = ts[io], loaded one output ahead
             if (tq > t * (1.0 + 1e-15)) break;
             double yq[V];
             MTRPL_ORDER_SWITCH(order, (ndf_dense<K, V>(D, tq, t, h, ih, yq)))
             emit(io, sigof(yq));
             io++;
+            tq_next = (io < nt) ? ts[io] : 1e300;
         }
         if (n_equal < order + 1) continue;
         // order / step-size selection

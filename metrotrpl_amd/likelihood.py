@@ -21,7 +21,7 @@ from . import batch
 class LikelihoodEngine:
     def __init__(self, indexes, units, lengths, nx, meas_types, times, vals, uncs, sigma, iniPar, ini_mode="fluence",
                  model="std", hmax=4.0, rtol=None, atol=None, irf_tables=None, irf_convolution=None,
-                 scale_shift=None, device=0, ctx=None):
+                 scale_shift=None, force_min_y=False, device=0, ctx=None):
         """times/vals/uncs: per-measurement 1-D arrays (as _times/_vals/_uncs of the
         reference's shared fields); sigma: {meas_type: model_uncertainty};
         irf_tables: {wavelength: (table [k,3], t_irf [k])} from make_I_tables;
@@ -51,6 +51,7 @@ class LikelihoodEngine:
         self.scale_shift = np.zeros(self.M) if scale_shift is None else np.asarray(scale_shift, dtype=np.float64)
         # IRF tables -> device (mtrpl_irf_tables_upload)
         self.irf_index = [-1] * self.M
+        self.force_min_y = bool(force_min_y)  # shared_fields["force_min_y"], trial_move_evaluation.py:136
         if irf_tables and irf_convolution is not None:
             waves = sorted({int(w) for w in irf_convolution if w})
             nk = np.array([irf_tables[w][0].shape[0] for w in waves], dtype=np.int32)
@@ -93,6 +94,7 @@ class LikelihoodEngine:
         ld["nt"] = d["nt"]
         ld["n_exp"] = d["nt"]
         ld["irf"] = np.tile(self.irf_index, Cn)
+        ld["force_min_y"] = int(self.force_min_y)
         ld["scale_shift"] = np.tile(self.scale_shift, Cn)
         ld["sigma"] = np.tile(self.sigma, Cn)
         return d, ini_arr, ld
