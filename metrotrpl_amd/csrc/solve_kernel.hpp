@@ -27,6 +27,7 @@ struct SolveTuning {
     int max_steps;
     double newton_tol;  // <= 0: SciPy's rule max(10 eps/rtol, min(0.03, sqrt(rtol))); else this value
     int rate_max_age;   // consecutive 1-iteration Newton solves allowed on a carried-over rate (0: always >= 2)
+    double rate_first_safety;  // > 0: after a refactorisation carry (this x first measured rate); 0: VODE smoothing only
 };
 
 // RMS norm over the 3nx+1 ODE components; v is already divided by the weights.
@@ -371,7 +372,11 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
                         double rp = rate;  // rate^(4-k)
                         for (int q = 1; q < 4 - k; ++q) rp *= rate;
                         if (rate >= 1.0 || rp * frcp(1.0 - rate) * dn > newton_tol) break;
-                        rate_prev = fmax(0.3 * rate_prev, rate);
+                        // first measurement with new factors: take it (x rate_first_safety) instead
+                        // of smoothing down from 1 over several two-iteration steps
+                        rate_prev = (rate_prev >= 1.0 && tune.rate_first_safety > 0.0)
+                                        ? fmin(fmax(tune.rate_first_safety * rate, 1e-4), 0.9)
+                                        : fmax(0.3 * rate_prev, rate);
                         rate_age = 0;
                     }
 #pragma unroll

@@ -247,7 +247,9 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
                         double rp = rate;  // rate^(4-k)
                         for (int q = 1; q < 4 - k; ++q) rp *= rate;
                         if (rate >= 1.0 || rp * frcp(1.0 - rate) * dn > newton_tol) break;
-                        rate_prev = fmax(0.3 * rate_prev, rate);
+                        rate_prev = (rate_prev >= 1.0 && tune.rate_first_safety > 0.0)
+                                        ? fmin(fmax(tune.rate_first_safety * rate, 1e-4), 0.9)
+                                        : fmax(0.3 * rate_prev, rate);
                         rate_age = 0;
                     }
 #pragma unroll
