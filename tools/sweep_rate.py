@@ -16,7 +16,7 @@ if __name__ == "__main__":
         refs = np.array(p.map(one, range(N), chunksize=4))
     from metrotrpl_amd import batch, _lib as L
     ctx = L.default_context()
-    for rfs, age, ntol in [(0.0, 8, 0.03), (4.0, 8, 0.03), (2.0, 8, 0.03), (4.0, 20, 0.03), (4.0, 8, 0.1), (10.0, 8, 0.03)]:
+    for rfs, age, ntol in [(4.0, 8, 0.03), (2.0, 20, 0.1), (2.0, 20, 0.2), (2.0, 20, 0.3), (1.0, 20, 0.3), (2.0, 20, 0.5), (1.0, 50, 0.5)]:
         ctx.set_option("rate_first_safety", rfs); ctx.set_option("rate_max_age", age); ctx.set_option("newton_tol", ntol)
         for rep in range(2):
             t0 = time.time()
