@@ -19,7 +19,7 @@ using namespace mtrpl;
 struct mtrpl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    SolveTuning tune{0.1, 5e-9, 5e-9, 1e-4, 2000000, 0.03, 8, 4.0};
+    SolveTuning tune{0.1, 3e-9, 1.5e-9, 1e-4, 2000000, 0.03, 8, 4.0};
     std::string err;
     // IRF tables resident on the device (mtrpl_irf_tables_upload)
     double *d_irf_tab = nullptr;

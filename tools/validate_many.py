@@ -18,8 +18,8 @@ if __name__ == "__main__":
     print("oracle done", time.time() - t0, flush=True)
     from metrotrpl_amd import batch, _lib as L
     ctx = L.default_context()
-    for rc in (1e-8, 7e-9, 5e-9):
-        ctx.set_option("rtol_cap", rc)
+    for rc in (5e-9, 3e-9, 2e-9, 1.5e-9):
+        ctx.set_option("rtol_cap", rc); ctx.set_option("rtol_floor", rc)
         sig, status, stats = batch.solve_batch(c["states"], ix, un, c["iniPar"], c["thickness"], c["nx"], c["tSteps"], return_stats=True)
         errs = []
         for k in range(N):
