@@ -107,6 +107,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one rank needs no process group; MTRPL_FORCE_DIST=1 makes a 1-rank run go through RCCL
+    # anyway (rehearsal of the N > 1 code path on a one-GPU box)
+    use_dist = world > 1 or os.environ.get("MTRPL_FORCE_DIST") == "1"
+    a.use_dist = use_dist
     # CPU baseline first: its worker processes are forked before this process touches the GPU
     cpu = None
     if rank == 0 and world == 1 and a.workload == "batch" and not a.no_cpu_baseline:
@@ -123,8 +127,11 @@ def main():
         sys.exit(3)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=dev)
 
     from metrotrpl_amd import _lib as L, batch, workloads as W
@@ -133,7 +140,7 @@ def main():
         line = pt_bench.run(a, rank, world, local, dev)
         if rank == 0:
             print(json.dumps(line))
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -162,7 +169,7 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
@@ -172,11 +179,11 @@ def main():
         step()
         ev[k][1].record(stream)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -215,7 +222,7 @@ def main():
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

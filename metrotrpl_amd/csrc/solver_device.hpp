@@ -3,9 +3,10 @@
 // One 64-lane wavefront integrates one forward simulation (forward_solver.py:41-203):
 // lane l owns R consecutive grid nodes (N_i, P_i) and the edge field E_i on the
 // LEFT face of each of them (i = l*R + r), so nx <= 64*R.  The whole solver state
-// (backward-difference history, Newton matrix factors) lives in this wave's
-// registers; HBM is touched for the per-solve descriptor, the initial condition,
-// the output sample times and the nt output samples only.
+// lives on the CU (backward-difference history and Newton vectors in this wave's
+// VGPRs/AGPRs, Newton matrix factors in its LDS slab); HBM is touched for the
+// per-solve descriptor, the initial condition, the output sample times and the nt
+// output samples only.
 //
 // Time integration: variable-order (1..5), quasi-constant-step NDF
 // (Shampine & Reichelt, "The MATLAB ODE Suite", SIAM J. Sci. Comput. 18, 1997;
@@ -16,10 +17,11 @@
 //     its own E_i, so E is eliminated per edge and the Newton matrix I - c*J
 //     becomes block tridiagonal with 2x2 blocks in (dN_i, dP_i);
 //   * that system solved across the wave by one in-lane cyclic-reduction level
-//     per doubling of R followed by 6 parallel-cyclic-reduction levels over the
-//     64 lanes (wave shuffles only, no LDS allocation, no barriers); all
-//     elimination factors are kept so each further Newton iteration is a
-//     cheap re-solve.
+//     followed by 6 parallel-cyclic-reduction levels over the 64 lanes
+//     (nearest-neighbour exchange by DPP wave shifts, longer strides by
+//     ds_bpermute; one wave per workgroup, so no barriers); all 17 elimination
+//     blocks per lane are kept in this wave's 34 KB LDS slab as 16-byte rows, so
+//     each further Newton iteration is a cheap re-solve.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -86,7 +86,7 @@ def run(a, rank, world, local, dev):
         k += 1
         ens.iterate(proposer, k % temper_freq == 0)
     torch.cuda.synchronize()
-    if world > 1:
+    if getattr(a, "use_dist", world > 1):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -95,11 +95,11 @@ def run(a, rank, world, local, dev):
         k += 1
         n_acc += int(ens.iterate(proposer, k % temper_freq == 0).sum())
     torch.cuda.synchronize()
-    if world > 1:
+    if getattr(a, "use_dist", world > 1):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if getattr(a, "use_dist", world > 1):
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
