@@ -235,18 +235,30 @@ __device__ inline double conv_interp(const ConvCtx &c, double v)
     return c.sb[q] * (v - c.st[q]) + c.sy[q];
 }
 
-// h[k] of laplace.py:204-210
-__device__ inline double conv_fast(const ConvCtx &c, int64_t k)
+// same interval as conv_segment, found by walking from a nearby guess q (consecutive
+// outputs and consecutive runs of one output move forward by at most an interval or two)
+__device__ inline int conv_segment_near(const ConvCtx &c, double v, int q)
+{
+    while (q < c.nt - 2 && c.st[q + 1] < v) ++q;
+    while (q > 0 && c.st[q] >= v) --q;
+    return q;
+}
+
+// h[k] of laplace.py:204-210.  qhint: interval guess for the first tap (in/out).
+__device__ inline double conv_fast(const ConvCtx &c, int64_t k, int &qhint)
 {
     if (k <= 0) return 0.0;
     const int64_t lo = (k - c.nk > 0) ? k - c.nk : 0, hi = k - 1;
     double acc = 0.0;
     int64_t cur = lo;
+    int q = qhint;
+    bool first = true;
     while (cur <= hi) {
         const double t0 = resampled_time(2 * cur, c.n_r, c.half_dt, c.t_end);
         const double t1 = resampled_time(2 * cur + 1, c.n_r, c.half_dt, c.t_end);
         const double t2 = resampled_time(2 * cur + 2, c.n_r, c.half_dt, c.t_end);
-        const int q = conv_segment(c, t1);
+        q = conv_segment_near(c, t1, q);
+        if (first) { qhint = q; first = false; }
         const bool regular = (t0 >= c.st[q]) && (t2 <= c.st[q + 1]) && (cur < c.nkk - 1);
         if (regular) {
             // last interval j of this run: tau_{2j+2} <= st[q+1]
@@ -337,9 +349,19 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
         // ---- pass A: argmax of the convolved trace (laplace.py:82) ----
         double best = 0.0;
         int64_t bi = nkk + 1;
-        for (int64_t k = tid; k <= nkk; k += kLikeBlock) {
-            const double acc = conv_fast(c, k);
-            if (argmax_better(acc, k, best, bi, nkk + 1)) { best = acc; bi = k; }
+        {
+            // contiguous run of outputs per thread: the interval guess carries over from k to k+1
+            const int64_t per = (nkk + kLikeBlock) / kLikeBlock;
+            const int64_t ka = (int64_t)tid * per, kb = (ka + per <= nkk + 1) ? ka + per : nkk + 1;
+            int qh = 0;
+            if (ka <= nkk) {
+                const int64_t lo0 = (ka - nk > 0) ? ka - nk : 0;
+                qh = conv_segment(c, resampled_time(2 * lo0 + 1, n_r, half_dt, t_end));
+            }
+            for (int64_t k = ka; k < kb; ++k) {
+                const double acc = conv_fast(c, k, qh);
+                if (argmax_better(acc, k, best, bi, nkk + 1)) { best = acc; bi = k; }
+            }
         }
         block_argmax(best, bi, nkk + 1, red_v, red_i);
         const double t_shift = resampled_time(2 * bi, n_r, half_dt, t_end);
@@ -373,7 +395,9 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
                 if (idx > nkk) idx = nkk;
                 const double x0 = resampled_time(2 * (idx - 1), n_r, half_dt, t_end) - t_shift;
                 const double x1 = resampled_time(2 * idx, n_r, half_dt, t_end) - t_shift;
-                const double h0 = conv_fast(c, idx - 1), h1 = conv_fast(c, idx);
+                const int64_t lo0 = (idx - 1 - nk > 0) ? idx - 1 - nk : 0;
+                int qh = conv_segment(c, resampled_time(2 * lo0 + 1, n_r, half_dt, t_end));
+                const double h0 = conv_fast(c, idx - 1, qh), h1 = conv_fast(c, idx, qh);
                 const double slope = (h1 - h0) / (x1 - x0);
                 v = slope * (te - x0) + h0;
             }
@@ -434,7 +458,7 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
         for (int j = tid; j < nT; j += kLikeBlock) {
             const double sT = sg2 * temps[j];
             double tot = 0.0;
-            for (int i = 0; i < n_c; ++i) tot += sol[i] / (sT + su2[i]);
+            for (int i = 0; i < n_c; ++i) tot += sol[i] * frcp(sT + su2[i]);  // frcp: ~1 ulp, no div ladder
             tot = -tot;
             if (failed || tot != tot) tot = -__builtin_inf();  // :70-72,:159-165
             ll[sidx * nT + j] = tot;
