@@ -1,0 +1,82 @@
+"""GPU: size-independent properties of the forward solve at BASELINE sizes (nx=128, 1001
+samples, config-2 draws) -- no oracle needed, so they run on a whole batch."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(n=256):
+    from metrotrpl_amd import workloads as W
+    c = W.config2(n)
+    return c, W.indexes(), W.units()
+
+
+def _win(a, floor=1e-4):
+    return np.abs(a) >= floor * np.abs(a[:, :1])
+
+
+def test_mirror_symmetry():
+    """Reversing the illumination AND swapping front/back surface velocities mirrors the film:
+    PL and TRTS are spatial integrals, so both signals are unchanged (exact symmetry of
+    forward_solver.py:346-352 with :111)."""
+    from metrotrpl_amd import batch
+    c, ix, un = _batch()
+    for meas in ("TRPL", "TRTS"):
+        a = batch.solve_batch(c["states"], ix, un, c["iniPar"], c["thickness"], c["nx"], c["tSteps"], meas=meas)
+        st = c["states"].copy()
+        st[:, [ix["Sf"], ix["Sb"]]] = st[:, [ix["Sb"], ix["Sf"]]]
+        ini = c["iniPar"].copy()
+        ini[:, 2] = -1
+        b = batch.solve_batch(st, ix, un, ini, c["thickness"], c["nx"], c["tSteps"], meas=meas)
+        m = _win(a)
+        assert np.max(np.abs(a[m] - b[m]) / np.abs(a[m])) < 1e-6, meas
+
+
+def test_output_grid_independence():
+    """The signal at a given time must not depend on which other sample times were asked for
+    (dense output of one and the same integration): 1001 vs 2001 vs 334 samples."""
+    from metrotrpl_amd import batch
+    c, ix, un = _batch(128)
+    t1 = np.linspace(0, 2000, 1001)
+    t2 = np.linspace(0, 2000, 2001)
+    t3 = np.linspace(0, 2000, 334)[:1] if False else np.linspace(0, 1998, 334)
+    a = batch.solve_batch(c["states"], ix, un, c["iniPar"], c["thickness"], c["nx"], t1)
+    b = batch.solve_batch(c["states"], ix, un, c["iniPar"], c["thickness"], c["nx"], t2)[:, ::2]
+    d = batch.solve_batch(c["states"], ix, un, c["iniPar"], c["thickness"], c["nx"], t3)
+    m = _win(a)
+    assert np.max(np.abs(a[m] - b[m]) / np.abs(a[m])) < 1e-6
+    a3 = a[:, ::3][:, :334]
+    m3 = _win(a3)
+    assert np.max(np.abs(a3[m3] - d[m3]) / np.abs(a3[m3])) < 1e-6
+
+
+def test_initial_sample_and_monotone_decay():
+    """sig[0] is the analytic integral of the Beer-Lambert profile; PL never increases for these
+    (source-free, recombination-only) problems."""
+    from metrotrpl_amd import batch
+    c, ix, un = _batch()
+    sig = batch.solve_batch(c["states"], ix, un, c["iniPar"], c["thickness"], c["nx"], c["tSteps"])
+    s = c["states"] * un
+    dx = c["thickness"] / c["nx"]
+    x = np.linspace(dx / 2, c["thickness"] - dx / 2, c["nx"])
+    dN = (c["iniPar"][:, 0] * 1e-14 * c["iniPar"][:, 1] * 1e-7)[:, None] * np.exp(-(c["iniPar"][:, 1] * 1e-7)[:, None] * x)
+    N, P = dN + s[:, [ix["n0"]]], dN + s[:, [ix["p0"]]]
+    pl0 = dx * np.sum(s[:, [ix["ks"]]] * (N * P - s[:, [ix["n0"]]] * s[:, [ix["p0"]]]), axis=1) * 1e23
+    np.testing.assert_allclose(sig[:, 0], pl0, rtol=1e-12)
+    m = _win(sig)
+    ok = (np.diff(sig, axis=1) <= 1e-9 * sig[:, :-1]) | ~m[:, 1:]
+    assert np.all(ok)
+
+
+def test_fluence_scaling_in_the_linear_regime():
+    """Low injection (dN << p0), no Auger/radiative dominance: PL - background scales linearly
+    with fluence (TRPL ~ ks p0 dN; the dN^2 term is 6e-7 of it at these fluences)."""
+    from metrotrpl_amd import batch, workloads as W
+    ix, un, s0 = W.indexes(), W.units(), W.initial_state()
+    s0 = s0.copy()
+    s0[ix["p0"]] = 1e16
+    t = np.linspace(0, 200, 101)
+    a = batch.solve_batch(s0[None, :], ix, un, [[1e5, 6e4, 1]], 2000.0, 128, t)[0]
+    b = batch.solve_batch(s0[None, :], ix, un, [[2e5, 6e4, 1]], 2000.0, 128, t)[0]
+    np.testing.assert_allclose(b / a, 2.0, rtol=1e-5)
