@@ -19,7 +19,7 @@ using namespace mtrpl;
 struct mtrpl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    SolveTuning tune{0.1, 3e-9, 1.5e-9, 1e-4, 2000000, 0.03, 8, 4.0};
+    SolveTuning tune{0.1, 3e-9, 1.5e-9, 1e-4, 2000000, 0.03, 8, 4.0, 1.0, 1};
     std::string err;
     // IRF tables resident on the device (mtrpl_irf_tables_upload)
     double *d_irf_tab = nullptr;
@@ -297,6 +297,8 @@ int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value)
     else if (k == "rate_max_age") ctx->tune.rate_max_age = (int)value;
     else if (k == "newton_tol") ctx->tune.newton_tol = value;
     else if (k == "rate_first_safety") ctx->tune.rate_first_safety = value;
+    else if (k == "e_weight") ctx->tune.e_weight = value;
+    else if (k == "honor_hmax") ctx->tune.honor_hmax = (int)value;
     else if (k == "kernel_variant") ctx->kernel_variant = (int)value;
     else return bad(ctx, MTRPL_ERR_BAD_ARG, "unknown option");
     return MTRPL_OK;
@@ -314,6 +316,8 @@ int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value)
     else if (k == "rate_max_age") *value = ctx->tune.rate_max_age;
     else if (k == "newton_tol") *value = ctx->tune.newton_tol;
     else if (k == "rate_first_safety") *value = ctx->tune.rate_first_safety;
+    else if (k == "e_weight") *value = ctx->tune.e_weight;
+    else if (k == "honor_hmax") *value = ctx->tune.honor_hmax;
     else if (k == "kernel_variant") *value = ctx->kernel_variant;
     else return MTRPL_ERR_BAD_ARG;
     return MTRPL_OK;

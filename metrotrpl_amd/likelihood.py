@@ -21,11 +21,14 @@ from . import batch
 class LikelihoodEngine:
     def __init__(self, indexes, units, lengths, nx, meas_types, times, vals, uncs, sigma, iniPar, ini_mode="fluence",
                  model="std", hmax=4.0, rtol=None, atol=None, irf_tables=None, irf_convolution=None,
-                 scale_shift=None, force_min_y=False, device=0, ctx=None):
+                 scale_shift=None, force_min_y=False, device=0, ctx=None, fittables=None):
         """times/vals/uncs: per-measurement 1-D arrays (as _times/_vals/_uncs of the
         reference's shared fields); sigma: {meas_type: model_uncertainty};
         irf_tables: {wavelength: (table [k,3], t_irf [k])} from make_I_tables;
-        irf_convolution: per-measurement wavelength or 0/None."""
+        irf_convolution: per-measurement wavelength or 0/None; nx: one value or one per
+        measurement; fittables: {"fluences"|"absps"|"scale": per-measurement index of the
+        state entry that multiplies iniPar[0] / iniPar[1] / sets scale_shift = log10(entry),
+        -1 = none} (trial_move_evaluation.py:38-60, see `fittable_indexes`)."""
         import torch
         self.torch = torch
         self.dev = torch.device("cuda", device)
@@ -33,7 +36,12 @@ class LikelihoodEngine:
         self.indexes, self.units = indexes, np.asarray(units, dtype=np.float64)
         self.M = len(lengths)
         self.lengths = np.asarray(lengths, dtype=np.float64)
-        self.nx, self.meas_types = int(nx), list(meas_types)
+        self.nx_list = np.broadcast_to(np.asarray(nx, dtype=np.int32), (self.M,)).copy()
+        self.nx, self.meas_types = int(self.nx_list.max()), list(meas_types)
+        if ini_mode == "density" and np.any(self.nx_list != self.nx):
+            raise NotImplementedError("density-mode initial conditions need one nx for all measurements")
+        self.fit = {k: np.asarray((fittables or {}).get(k, [-1] * self.M), dtype=np.int64)
+                    for k in ("fluences", "absps", "scale")}
         self.iniPar = np.atleast_2d(np.asarray(iniPar, dtype=np.float64))
         self.ini_mode, self.model, self.hmax, self.rtol, self.atol = ini_mode, model, hmax, rtol, atol
         times = [np.ascontiguousarray(t, dtype=np.float64) for t in times]
@@ -78,12 +86,25 @@ class LikelihoodEngine:
         Cn = states.shape[0]
         st = np.repeat(states, self.M, axis=0)
         ini = np.tile(self.iniPar, (Cn, 1))
+        shift = np.tile(self.scale_shift, Cn)
+        rows = np.repeat(np.arange(Cn), self.M)
+        for key, col in (("fluences", 0), ("absps", 1)):
+            idx = np.tile(self.fit[key], Cn)
+            use = idx >= 0
+            if use.any():  # a COPY of the init row is scaled (the reference compounds in place, :44/:51)
+                ini[use, col] *= states[rows[use], idx[use]]
+        idx = np.tile(self.fit["scale"], Cn)
+        use = idx >= 0
+        if use.any():
+            with np.errstate(divide="ignore", invalid="ignore"):
+                shift[use] = np.log10(states[rows[use], idx[use]])
         thick = np.tile(self.lengths, Cn)
         meas = self.meas_types * Cn
         per_chain = int(np.sum(self.nts))
         out_off = (np.repeat(np.arange(Cn, dtype=np.int64), self.M) * per_chain + np.tile(self.t_off, Cn))
         d, ini_arr = batch.build_batch(st, self.indexes, self.units, ini, thick, self.nx, 1, hmax=self.hmax, meas=meas,
                                        model=self.model, ini_mode=self.ini_mode, RTOL=self.rtol, ATOL=self.atol)
+        d["nx"] = np.tile(self.nx_list, Cn)
         d["nt"] = np.tile(self.nts, Cn)
         d["t_off"] = np.tile(self.t_off, Cn)
         d["out_off"] = out_off
@@ -95,7 +116,7 @@ class LikelihoodEngine:
         ld["n_exp"] = d["nt"]
         ld["irf"] = np.tile(self.irf_index, Cn)
         ld["force_min_y"] = int(self.force_min_y)
-        ld["scale_shift"] = np.tile(self.scale_shift, Cn)
+        ld["scale_shift"] = shift
         ld["sigma"] = np.tile(self.sigma, Cn)
         return d, ini_arr, ld
 
@@ -131,3 +152,45 @@ class LikelihoodEngine:
         ll = self.launch(d_T, len(T))
         torch.cuda.synchronize()
         return ll.cpu().numpy().reshape(-1, self.M, len(T))
+
+
+def fittable_indexes(shared_fields):
+    """Resolve the reference's fittable_fluences / fittable_absps / scale_factor specs
+    ([move size, measurement indices, constraint groups, guesses]) to, per measurement, the
+    index of the `_f{g}` / `_a{g}` / `_s{g}` state entry it uses (g = first member of the
+    measurement's constraint group, utils.py:4-14), -1 where the measurement has none."""
+    M = shared_fields["_sim_info"]["num_meas"]
+    pidx = shared_fields["_param_indexes"]
+    out = {}
+    for key, field, prefix in (("fluences", "fittable_fluences", "_f"), ("absps", "fittable_absps", "_a"),
+                               ("scale", "scale_factor", "_s")):
+        spec = shared_fields.get(field, None)
+        idx = [-1] * M
+        if spec is not None:
+            for m in range(M):
+                if m not in spec[1]:
+                    continue
+                g = m
+                for grp in (spec[2] or []):
+                    if m in grp:
+                        g = grp[0]
+                        break
+                idx[m] = pidx[f"{prefix}{g}"]
+        out[key] = idx
+    return out
+
+
+def engine_from_fields(shared_fields, unique_fields, device=0, ctx=None):
+    """A LikelihoodEngine for the ensemble described by the reference's shared/unique
+    field dictionaries (sim_utils.py:98-199 + the `_times/_vals/_uncs/_init_params/
+    _IRF_tables` entries metro() adds, metropolis.py:325-342)."""
+    sf = shared_fields
+    si = sf["_sim_info"]
+    if "solver" in sf and sf["solver"][0] not in ("solveivp", "odeint", "diagnostic"):
+        raise NotImplementedError("No solver available")  # forward_solver.py:225 (the NN surrogate is out of scope)
+    return LikelihoodEngine(sf["_param_indexes"], sf["units"], si["lengths"], si["nx"], si["meas_types"],
+                            sf["_times"], sf["_vals"], sf["_uncs"], unique_fields["model_uncertainty"],
+                            sf["_init_params"], ini_mode=sf["ini_mode"], model=sf["model"], hmax=sf["hmax"],
+                            rtol=sf.get("rtol"), atol=sf.get("atol"), irf_tables=sf.get("_IRF_tables") or None,
+                            irf_convolution=sf.get("irf_convolution"), force_min_y=sf.get("force_min_y", False),
+                            device=device, ctx=ctx, fittables=fittable_indexes(sf))

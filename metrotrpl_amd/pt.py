@@ -110,6 +110,31 @@ def replica_exchange(table, rng):
     return owner, attempts, accepts
 
 
+def gather_ll_table(evaluator, states, temperatures, blocks, rank=0, world=1, group=None):
+    """Evaluate this rank's block of chain states at all ladder temperatures and
+    all-gather the [n_chains, nT] table (one collective; RCCL on GPUs, gloo in CPU tests)."""
+    import torch
+    import torch.distributed as dist
+    lo, hi = blocks[rank]
+    n = blocks[-1][1]
+    local = evaluator(states[lo:hi], temperatures)
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return local.detach().cpu().numpy()
+    sizes = [b[1] - b[0] for b in blocks]
+    if len(set(sizes)) == 1:
+        full = torch.empty((n, local.shape[1]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(full, local.contiguous(), group=group)
+    else:
+        # uneven blocks: collectives want equal shapes, so pad to the largest block
+        mx = max(sizes)
+        padded = torch.zeros((mx, local.shape[1]), dtype=local.dtype, device=local.device)
+        padded[:local.shape[0]] = local
+        buf = torch.empty((world * mx, local.shape[1]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(buf, padded, group=group)
+        full = torch.cat([buf[r * mx:r * mx + s] for r, s in enumerate(sizes)], dim=0)
+    return full.cpu().numpy()
+
+
 class PTEnsemble:
     """One rank's view of the sharded ensemble.
 
@@ -132,24 +157,7 @@ class PTEnsemble:
 
     def gather_table(self, states):
         """Evaluate the local block at all ladder temperatures, all-gather -> [n, nT] numpy."""
-        import torch
-        import torch.distributed as dist
-        local = self.evaluator(states[self.lo:self.hi], self.T)
-        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
-            return local.detach().cpu().numpy()
-        sizes = [b[1] - b[0] for b in self.blocks]
-        if len(set(sizes)) == 1:
-            full = torch.empty((self.n, local.shape[1]), dtype=local.dtype, device=local.device)
-            dist.all_gather_into_tensor(full, local.contiguous(), group=self.group)
-        else:
-            # uneven blocks: collectives want equal shapes, so pad to the largest block
-            mx = max(sizes)
-            padded = torch.zeros((mx, local.shape[1]), dtype=local.dtype, device=local.device)
-            padded[:local.shape[0]] = local
-            buf = torch.empty((self.world * mx, local.shape[1]), dtype=local.dtype, device=local.device)
-            dist.all_gather_into_tensor(buf, padded, group=self.group)
-            full = torch.cat([buf[r * mx:r * mx + s] for r, s in enumerate(sizes)], dim=0)
-        return full.cpu().numpy()
+        return gather_ll_table(self.evaluator, states, self.T, self.blocks, self.rank, self.world, self.group)
 
     def initialise(self):
         self.table = self.gather_table(self.states)

@@ -1,0 +1,180 @@
+"""Host logic of the batched Metropolis / parallel-tempering driver against walks
+produced by the reference's own serial loop (tests/golden/mcmc.npz).  The table
+evaluator injected here is the CPU oracle, so this runs without a GPU; the GPU
+counterpart is tests/test_gpu_metropolis.py."""
+import copy
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+
+from metrotrpl_amd import metropolis as M
+from metrotrpl_amd import sim_utils as S
+from metrotrpl_amd.trial_move_generation import approve_move, make_trial_move
+from oracle import oracle as O
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from mcmc_common import check_walk, load_case  # noqa: E402
+
+
+def oracle_gather(E):
+    ef, uf = E.ensemble_fields, E.unique_fields
+    T = np.asarray(ef["_T"], dtype=float)
+
+    def gather(states):
+        out = np.empty((states.shape[0], len(T)))
+        for c in range(states.shape[0]):
+            _, table = O.eval_trial_move(states[c].copy(), uf[c], ef, temperatures=T)
+            out[c] = table.sum(axis=0)
+        return out
+    return gather
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    O.build()
+
+
+def run_walk(name, **kw):
+    E, num_iters, ref = load_case(name, O.make_I_tables)
+    RNG = np.random.default_rng(M.SEED)
+    walk = M.Walk(E.ensemble_fields, E.unique_fields, RNG, oracle_gather(E), rng_mode="serial", **kw)
+    walk.run(E.H.states, E.H.loglikelihood, E.H.accept, 0, num_iters, need_initial_state=True)
+    return E, walk, ref
+
+
+def test_single_chain_walk_matches_reference_serial_loop():
+    E, walk, ref = run_walk("single")
+    assert ref["accept"].sum() >= 5  # the golden walk does move
+    check_walk(E, walk, ref, rtol_ll=1e-7)
+
+
+def test_parallel_tempering_walk_matches_reference_serial_loop():
+    # the serial reference's swap is a tuple swap of numpy views (metropolis.py:85): reproduce it
+    E, walk, ref = run_walk("pt", serial_swap_aliasing=True)
+    assert ref["swap_accept"].sum() >= 3
+    check_walk(E, walk, ref, rtol_ll=1e-7)
+
+
+def test_correct_swap_keeps_both_states():
+    E, walk, ref = run_walk("pt")
+    k_first = 2  # first tempering iteration (temper_freq 2)
+    H = E.H
+    # up to the first accepted swap the walks agree; afterwards the ensemble still holds n distinct states
+    np.testing.assert_allclose(H.states[:, :, :k_first], ref["states"][:, :, :k_first], rtol=1e-12)
+    last = H.states[:, :, -1]
+    assert len({tuple(r) for r in last}) == last.shape[0]
+    # log-likelihood bookkeeping stays consistent with the table rows
+    n = last.shape[0]
+    np.testing.assert_array_equal(H.loglikelihood[:, -1], walk.table[np.arange(n), np.arange(n)])
+
+
+def test_mpi_draw_order_gives_every_chain_the_same_uniforms():
+    E, num_iters, _ = load_case("pt", O.make_I_tables)
+    ef = E.ensemble_fields
+    calls = []
+
+    def fake_gather(states):
+        calls.append(states.copy())
+        return -np.ones((states.shape[0], len(ef["_T"])))
+    walk = M.Walk(ef, E.unique_fields, np.random.default_rng(1), fake_gather, rng_mode="mpi")
+    walk.run(E.H.states, E.H.loglikelihood, E.H.accept, 0, 2, need_initial_state=True)
+    prop = calls[1]
+    cur = E.H.states[:, :, 0]
+    step = np.log10(prop) - np.log10(cur)
+    active = ef["base_trial_move"] > 0
+    # identical generators: displacement / (sqrt(T) * base move) is the same vector for every chain
+    unit = step[:, active] / (np.sqrt(ef["_T"])[:, None] * ef["base_trial_move"][active][None, :])
+    np.testing.assert_allclose(unit[1], unit[0], rtol=1e-9)
+    np.testing.assert_allclose(unit[2], unit[0], rtol=1e-9)
+
+
+def test_make_trial_move_bounds_and_inactive_params():
+    # the scenario of the reference's Tests/test_make_trial_move.py:23-69
+    names = ["a", "b", "c", "d"]
+    sf = {"do_log": np.array([0, 1, 0, 0], dtype=bool), "active": np.array([0, 1, 1, 1], dtype=bool),
+          "prior_dist": {n: (-np.inf, np.inf) for n in names}, "_param_indexes": {n: i for i, n in enumerate(names)},
+          "names": names}
+    move = np.array([0, 0.1, 0, 1.0])
+    state = [0, 100, 0, 10]
+    rng = np.random.default_rng(1)
+    for _ in range(100):
+        new = make_trial_move(state, move, sf, rng)
+        assert new[0] == 0 and new[2] == 0
+        assert abs(np.log10(new[1]) - 2) <= 0.1 and abs(new[3] - 10) <= 1
+
+
+def test_approve_move_checks():
+    names = ["n0", "p0", "tauN", "tauP"]
+    sf = {"do_log": np.ones(4, dtype=bool), "active": np.ones(4, dtype=bool), "names": names,
+          "prior_dist": {"n0": (0, np.inf), "p0": (1e14, 1e16), "tauN": (1, 1500), "tauP": (1, 3000)},
+          "_param_indexes": {n: i for i, n in enumerate(names)}}
+    assert approve_move(np.log10([1e8, 1e15, 100, 200]), sf) == []
+    assert "p0_size" in approve_move(np.log10([1e8, 1e17, 100, 200]), sf)
+    assert "p0_greater" in approve_move(np.log10([1e15, 1e14 * 1.1, 100, 200]), sf)
+    assert "tn_tp_close" in approve_move(np.log10([1e8, 1e15, 2, 2000]), sf)
+
+
+def test_history_extend_truncate_and_pickle_roundtrip(tmp_path):
+    E, num_iters, ref = load_case("single", O.make_I_tables)
+    E.H.states[:] = ref["states"]
+    E.latest_iter = 7
+    fn = tmp_path / "e.pik"
+    E.checkpoint(str(fn))
+    raw = fn.read_bytes()
+    assert b"sim_utils" in raw and b"metrotrpl_amd" not in raw  # recorded under the reference's class path
+    E2 = S.load_pickle(str(fn))
+    assert isinstance(E2, S.Ensemble) and E2.latest_iter == 7
+    np.testing.assert_array_equal(E2.H.states, ref["states"])
+    assert E2.H.mean_tauN.shape == (1, num_iters)
+    E2.H.extend(num_iters + 5)
+    assert E2.H.states.shape[2] == num_iters + 5 and E2.H.accept.shape[1] == num_iters + 5
+    E2.H.extend(10)
+    assert E2.H.loglikelihood.shape[1] == 10
+
+
+def test_metro_checkpoint_resume_is_the_same_walk(tmp_path):
+    """The property Tests/test_checkpoint.py pins: stopping at a checkpoint and resuming
+    gives the identical walk."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mcmc.npz"))
+    import json
+    cfg = json.loads(str(z["pt__config"]))
+
+    def fields(num_iters, ckpt_freq, load):
+        pi, si, mf = copy.deepcopy(cfg["param_info"]), copy.deepcopy(cfg["sim_info"]), copy.deepcopy(cfg["MCMC_fields"])
+        pi["prior_dist"] = {k: tuple(v) for k, v in pi["prior_dist"].items()}
+        mf.update(num_iters=num_iters, checkpoint_freq=ckpt_freq, load_checkpoint=load, output_path=str(tmp_path),
+                  irf_convolution=None)
+        return si, pi, mf
+    times = z["pt__times"]
+    e_data = ([times, times], [v for v in z["pt__vals"]], [u for u in z["pt__uncs"]])
+
+    class G:  # cheap deterministic stand-in for the simulator: a smooth function of the state
+        def __init__(self, T):
+            self.T = np.asarray(T, dtype=float)
+
+        def __call__(self, states):
+            base = -np.sum((np.log10(states[:, [9, 10]]) - np.log10([300.0, 600.0])) ** 2, axis=1) * 40
+            return base[:, None] / self.T[None, :]
+    T = cfg["MCMC_fields"]["parallel_tempering"]
+    si, pi, mf = fields(12, 12, None)
+    full = M.metro(si, z["pt__iniPar"].copy(), e_data, mf, pi, export_path="full.pik", serial_fallback=True,
+                   gather=G(T), logger_name="full")
+    si, pi, mf = fields(12, 6, None)
+    M.metro(si, z["pt__iniPar"].copy(), e_data, mf, pi, export_path="part.pik", serial_fallback=True, gather=G(T),
+            logger_name="part")
+    first = S.load_pickle(str(tmp_path / "part.pik"))
+    assert first.latest_iter == 12
+    # interrupted run: write a checkpoint at 6, then resume from it
+    si, pi, mf = fields(6, 6, None)
+    M.metro(si, z["pt__iniPar"].copy(), e_data, mf, pi, export_path="half.pik", serial_fallback=True, gather=G(T),
+            logger_name="half")
+    si, pi, mf = fields(12, 6, "half.pik")
+    resumed = M.metro(si, z["pt__iniPar"].copy(), e_data, mf, pi, export_path="resumed.pik", serial_fallback=True,
+                      gather=G(T), logger_name="resumed")
+    np.testing.assert_array_equal(first.H.states, full.H.states)
+    np.testing.assert_array_equal(resumed.H.states[:, :, :6], full.H.states[:, :, :6])
+    assert resumed.H.states.shape == full.H.states.shape
+    assert full.H.accept.sum() > 0
