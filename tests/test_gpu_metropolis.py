@@ -69,3 +69,36 @@ def test_metro_entry_point_on_gpu(tmp_path):
     assert back.latest_iter == mf.get("num_iters", 24) or back.latest_iter == 24
     np.testing.assert_array_equal(back.H.states, E.H.states)
     assert back.H.mean_tauN.shape == (3, 24)
+
+
+def test_main_from_config_script_and_csv_files(tmp_path, monkeypatch):
+    """The whole reference workflow from files: config script (written by the reference's
+    generator: tests/golden/configs/default_terse.txt, paths re-pointed), initial-condition
+    CSV, stacked measurement CSV -> metro -> pickle."""
+    from metrotrpl_amd import forward_solver, main, sim_utils as S, workloads as W
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    text = open(os.path.join(golden, "configs", "default_terse.txt")).read()
+    text = text.replace("Inputs/fluences.csv", str(tmp_path / "flu.csv")).replace(
+        "Inputs/meas.csv", str(tmp_path / "meas.csv")).replace("bay_outputs/run", str(tmp_path / "out")).replace(
+        "Num iters: 100", "Num iters: 6").replace("Time cutoffs: 0\t2000", "Time cutoffs: 0\t200")
+    (tmp_path / "mcmc0.txt").write_text(text)
+    ini = np.array(W.STAUB_FLUENCES, dtype=float)
+    np.savetxt(tmp_path / "flu.csv", ini, delimiter=",")
+    times = np.linspace(0, 400, 201)
+    ix, un, s0 = W.indexes(), W.units(), W.initial_state()
+    rows = []
+    for m in range(6):
+        g = S.Grid(W.STAUB_LENGTHS[m], 128, times, 4.0)
+        sig = forward_solver.solve(np.array(ini[m]), g, s0.copy(), ix, units=un, ini_mode="fluence")
+        rows.append(np.stack([times, sig, 0.05 * sig], axis=1))
+    np.savetxt(tmp_path / "meas.csv", np.concatenate(rows), delimiter=",")
+    monkeypatch.chdir(tmp_path)
+    ens = main.run("mcmc", 0)
+    assert ens.H.states.shape == (1, 13, 6)
+    assert len(ens.ensemble_fields["_times"]) == 6 and len(ens.ensemble_fields["_times"][0]) == 101  # cut to 200 ns
+    # the data were simulated at the initial guess: its log-likelihood is ~0 and never gets worse than a move allows
+    assert -1e-6 < ens.H.loglikelihood[0, 0] <= 0
+    assert np.all(np.isfinite(ens.H.loglikelihood))
+    back = S.load_pickle(str(tmp_path / "out" / "CPU0-final.pik"))
+    np.testing.assert_array_equal(back.H.states, ens.H.states)
+    assert back.ensemble_fields["ini_mode"] == "fluence" and back.latest_iter == 6
