@@ -140,3 +140,61 @@ def test_propose_respects_box_and_physics():
     # NaN proposal likelihood is rejected (metropolis.py:49-51)
     acc = pt.metropolis_accept(np.array([-5.0, -5.0, -5.0]), np.array([np.nan, -np.inf, 10.0]), np.random.default_rng(1))
     assert list(acc) == [False, False, True]
+
+
+# ---- the reference-order driver (metropolis.Walk) with chains sharded over ranks ------------------
+def _walk_fields(n_chains):
+    names = W.PARAM_NAMES
+    active = np.array([n in W.PRIOR_BOX for n in names])
+    ens0 = W.pt_ensemble(n_chains)
+    sf = {"names": list(names), "do_log": np.ones(len(names), dtype=bool), "active": active,
+          "prior_dist": {n: W.PRIOR_BOX.get(n, (0, np.inf)) for n in names}, "_param_indexes": W.indexes(),
+          "base_trial_move": np.where(active, 0.05, 0.0), "hard_bounds": 1, "_n_chains": n_chains,
+          "_T": list(ens0["temperatures"]), "do_parallel_tempering": True, "temper_freq": 2}
+    uf = [{"_T": t} for t in ens0["temperatures"]]
+    return sf, uf, ens0["chain_states"]
+
+
+def _walk_run(n_chains, iters, mode, rank=0, world=1):
+    from metrotrpl_amd import metropolis as M
+    sf, uf, st0 = _walk_fields(n_chains)
+    blocks = pt.partition(n_chains, world)
+
+    def gather(states):
+        return pt.gather_ll_table(_toy_evaluator, states, np.asarray(sf["_T"]), blocks, rank, world)
+    states = np.zeros((n_chains, st0.shape[1], iters))
+    states[:, :, 0] = st0
+    logll = np.zeros((n_chains, iters))
+    accept = np.zeros((n_chains, iters), dtype=int)
+    walk = M.Walk(sf, uf, np.random.default_rng(M.SEED), gather, rng_mode=mode)
+    walk.run(states, logll, accept, 0, iters, need_initial_state=True)
+    return states, logll, accept, walk.swap_accept.copy()
+
+
+def _walk_worker(rank, world, port, n_chains, iters, mode, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q.put((rank,) + _walk_run(n_chains, iters, mode, rank, world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["serial", "mpi"])
+def test_reference_order_walk_sharded_equals_one_rank(mode):
+    n_chains, iters, world = 5, 9, 2
+    ref = _walk_run(n_chains, iters, mode)
+    assert ref[2].sum() > 0 and ref[3].sum() > 0  # moves and swaps do happen
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_walk_worker, args=(r, world, port, n_chains, iters, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=90) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        for got, want in zip(r[1:], ref):
+            np.testing.assert_array_equal(got, want)
