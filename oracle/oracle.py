@@ -22,6 +22,17 @@ from sys import float_info
 import numpy as np
 from scipy.integrate import odeint, solve_ivp
 
+try:
+    from threadpoolctl import threadpool_limits
+
+    def _one_blas_thread():
+        return threadpool_limits(limits=1, user_api="blas")
+except ImportError:  # pragma: no cover
+    import contextlib
+
+    def _one_blas_thread():
+        return contextlib.nullcontext()
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libmtrpl_oracle.so")
 
@@ -235,6 +246,13 @@ def solve(iniPar, g, state, indexes, meas="TRPL", units=None, solver=("solveivp"
         raise ValueError(f"Invalid model {model}")
 
     f = MODELS[model]
+    # LSODA factorises its dense Jacobian with LAPACK: one BLAS thread, so that the golden traces
+    # (generated single-threaded) are reproduced bit for bit whatever the host's core count
+    with _one_blas_thread():
+        return _integrate_and_reduce(f, args, solver, model, g, init_condition, s, ix, meas, RTOL, ATOL, stats)
+
+
+def _integrate_and_reduce(f, args, solver, model, g, init_condition, s, ix, meas, RTOL, ATOL, stats):
     if solver[0] in ("solveivp", "diagnostic"):
         sol = solve_ivp(lambda t, y: f(t, y, *args), [g.start_time, g.final_time], init_condition,
                         method="LSODA", dense_output=True, max_step=g.hmax, rtol=RTOL, atol=ATOL)

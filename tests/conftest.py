@@ -1,6 +1,10 @@
 import os
 import sys
 
+# golden traces were generated with one BLAS thread (LSODA's dense LU is summation-order sensitive)
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
+
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
