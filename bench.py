@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--workload", default="batch", choices=["batch", "pt"])
     ap.add_argument("--chains", type=int, default=512, help="--workload pt: total PT chains (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="integrator option for experiments (mtrpl_set_option); reported in config.options")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -145,6 +147,9 @@ def main():
         return
 
     ctx = L.Context(local)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, float(v))
     B = a.batch
     # rank r takes draws [r*B, (r+1)*B) of the seeded config-2 stream
     c = W.config2(B * world)
@@ -212,7 +217,8 @@ def main():
                                    "1001 output times over 2000 ns, hmax=4, std model, TRPL, rtol 1e-7 / atol 1e-10",
                        "solves_per_gpu_per_step": B, "nx": int(c["nx"]), "nt_out": int(nt), "parallelism": f"batch-shard x{world}",
                        "all_solves_ok": ok, "mean_integrator_steps": float(stats[:, 0].mean()),
-                       "mean_rhs_evals": float(stats[:, 1].mean())},
+                       "mean_rhs_evals": float(stats[:, 1].mean()), "max_integrator_steps": int(stats[:, 0].max()),
+                       **({"options": a.opt} if a.opt else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "solve_kernel_r2",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_solve": A,

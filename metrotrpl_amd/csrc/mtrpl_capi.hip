@@ -13,13 +13,14 @@
 #include "../../include/metrotrpl_amd.h"
 #include "irf_kernels.hpp"
 #include "solve_kernel_blk.hpp"
+#include "mtrpl_fp32_pass.hpp"
 
 using namespace mtrpl;
 
 struct mtrpl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    SolveTuning tune{0.1, 3e-9, 1.5e-9, 1e-4, 2000000, 0.03, 8, 4.0, 1.0, 1};
+    SolveTuning tune{0.1, 4e-9, 3e-10, 1e-4, 2000000, 0.03, 8, 4.0, 1.0, 1, 0.5, 16.0};
     std::string err;
     // IRF tables resident on the device (mtrpl_irf_tables_upload)
     double *d_irf_tab = nullptr;
@@ -31,6 +32,7 @@ struct mtrpl_ctx {
     double2 *d_gblk = nullptr;
     size_t gblk_bytes = 0;
     int kernel_variant = 0;  // 0: tuned wave kernel for std nx<=128; 1: always the team kernel
+    int precision = 64;      // 64: fp64 (the product); 32: the fp32 build of the team kernel (precision sweep only)
 };
 
 #define HIP_TRY(ctx, expr)                                                                   \
@@ -245,6 +247,20 @@ void launch_blk(hipStream_t s, int64_t B, const mtrpl_solve_desc *d_descs, const
                        d_tsteps, d_out, d_status, d_stats, B, tune, gblk);
 }
 
+// fp32 build of the team kernel (mtrpl_fp32_pass.hpp); std model only
+template <int W, bool GBLK>
+void launch_blk32(hipStream_t s, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
+                  const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats,
+                  const SolveTuning &t, double2 *gblk)
+{
+    const mtrpl32::mtrpl::SolveTuning t32{(float)t.rtol_scale, (float)t.rtol_cap, (float)t.rtol_floor,
+                                          (float)t.atol_rel, t.max_steps, (float)t.newton_tol, t.rate_max_age,
+                                          (float)t.rate_first_safety, (float)t.e_weight, t.honor_hmax,
+                                          (float)t.trts_rtol_factor, (float)t.amp_ref};
+    hipLaunchKernelGGL((mtrpl32::mtrpl::solve_kernel_blk<W, false, GBLK>), dim3((unsigned)B), dim3(64 * W), 0, s,
+                       d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, B, t32, reinterpret_cast<float2 *>(gblk));
+}
+
 }  // namespace
 
 extern "C" {
@@ -299,7 +315,13 @@ int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value)
     else if (k == "rate_first_safety") ctx->tune.rate_first_safety = value;
     else if (k == "e_weight") ctx->tune.e_weight = value;
     else if (k == "honor_hmax") ctx->tune.honor_hmax = (int)value;
+    else if (k == "trts_rtol_factor") ctx->tune.trts_rtol_factor = value;
+    else if (k == "amp_ref") ctx->tune.amp_ref = value;
     else if (k == "kernel_variant") ctx->kernel_variant = (int)value;
+    else if (k == "precision") {
+        if (value != 32 && value != 64) return bad(ctx, MTRPL_ERR_BAD_ARG, "precision must be 32 or 64");
+        ctx->precision = (int)value;
+    }
     else return bad(ctx, MTRPL_ERR_BAD_ARG, "unknown option");
     return MTRPL_OK;
 }
@@ -318,7 +340,10 @@ int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value)
     else if (k == "rate_first_safety") *value = ctx->tune.rate_first_safety;
     else if (k == "e_weight") *value = ctx->tune.e_weight;
     else if (k == "honor_hmax") *value = ctx->tune.honor_hmax;
+    else if (k == "trts_rtol_factor") *value = ctx->tune.trts_rtol_factor;
+    else if (k == "amp_ref") *value = ctx->tune.amp_ref;
     else if (k == "kernel_variant") *value = ctx->kernel_variant;
+    else if (k == "precision") *value = ctx->precision;
     else return MTRPL_ERR_BAD_ARG;
     return MTRPL_OK;
 }
@@ -335,6 +360,26 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;  // exactly the caller's stream (NULL = the default stream)
     const bool traps = model == MTRPL_MODEL_TRAPS;
+    if (ctx->precision == 32) {
+        if (traps) return bad(ctx, MTRPL_ERR_UNSUPPORTED, "the fp32 build covers the std model only");
+        if (max_nx <= 128) {
+            launch_blk32<1, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr);
+        } else if (max_nx <= 256) {
+            launch_blk32<2, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr);
+        } else {
+            const size_t need = (size_t)B * team_blk_bytes<4>();
+            if (need > ctx->gblk_bytes) {
+                if (ctx->d_gblk) (void)hipFree(ctx->d_gblk);
+                ctx->d_gblk = nullptr;
+                ctx->gblk_bytes = 0;
+                HIP_TRY(ctx, hipMalloc((void **)&ctx->d_gblk, need));
+                ctx->gblk_bytes = need;
+            }
+            launch_blk32<4, true>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, ctx->d_gblk);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        return MTRPL_OK;
+    }
     if (max_nx <= 128) {
         if (!traps && ctx->kernel_variant == 0)
             hipLaunchKernelGGL(solve_kernel_r2, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,

@@ -2,10 +2,17 @@
 // Mirrors forward_solver.solve (forward_solver.py:41-203): initial condition
 // (:100-122), stiff integration sampled at g.tSteps (:163-168), PL / TRTS
 // spatial integral (:186-197, :228-274), unit scale and min_y clamp (:189-192).
-#pragma once
+// (no #pragma once: mtrpl_fp32_pass.hpp compiles this file a second time with `double` read as `float`)
+#if (!defined(MTRPL_FP32_PASS) && !defined(MTRPL_SOLVE_KERNEL_HPP_F64)) || (defined(MTRPL_FP32_PASS) && !defined(MTRPL_SOLVE_KERNEL_HPP_F32))
+#ifdef MTRPL_FP32_PASS
+#define MTRPL_SOLVE_KERNEL_HPP_F32
+#else
+#define MTRPL_SOLVE_KERNEL_HPP_F64
+#endif
 #include "solver_device.hpp"
 
 // Diagnostic build only (-DMTRPL_STAMPS): s_memtime per phase; the real kernel has no stamps.
+#ifndef MTRPL_STAMP
 #ifdef MTRPL_STAMPS
 #define MTRPL_STAMP(acc)                                        \
     do {                                                        \
@@ -15,6 +22,7 @@
     } while (0)
 #else
 #define MTRPL_STAMP(acc) do { } while (0)
+#endif
 #endif
 
 namespace mtrpl {
@@ -30,6 +38,8 @@ struct SolveTuning {
     double rate_first_safety;  // > 0: after a refactorisation carry (this x first measured rate); 0: VODE smoothing only
     double e_weight;    // relative error weight of the field components = e_weight * rtol_int
     int honor_hmax;     // 1: desc.hmax caps the step (the reference's max_step); 0: error control alone
+    double trts_rtol_factor;  // internal rtol of TRTS solves = this x that of TRPL solves (not below rtol_floor)
+    double amp_ref;           // > 0: internal rtol /= max(1, (1 + tauP/tauN) / amp_ref); 0: off
 };
 
 // RMS norm over the 3nx+1 ODE components; v is already divided by the weights.
@@ -88,6 +98,7 @@ __device__ inline void change_D(double (&D)[8][V], int order, double factor, int
 // ---- order-specialised pieces of the NDF step -----------------------------------
 // `order` is wave-uniform, so a scalar switch picks one of five fully static
 // bodies: no per-row predication, and every D[k][v] has a fixed register.
+#ifndef MTRPL_ORDER_SWITCH
 #define MTRPL_ORDER_SWITCH(order_, CALL)      \
     switch (order_) {                          \
         case 1: { constexpr int K = 1; CALL; } break; \
@@ -96,6 +107,7 @@ __device__ inline void change_D(double (&D)[8][V], int order, double factor, int
         case 4: { constexpr int K = 4; CALL; } break; \
         default: { constexpr int K = 5; CALL; } break; \
     }
+#endif
 
 template <int K, int V>
 __device__ inline void ndf_predict(const double (&D)[8][V], double (&yp)[V], double (&psi)[V])
@@ -169,6 +181,7 @@ __device__ inline double signal_of(const Par &p, const double (&y)[3 * R], int m
     return uniform(wave_sum(s) * p.dx * scale);
 }
 
+#ifndef MTRPL_FP32_PASS  // the tuned wave kernel exists in fp64 only
 __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc *__restrict__ descs,
                                                           const double *__restrict__ ini,
                                                           const double *__restrict__ tsteps,
@@ -241,7 +254,16 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
     for (int s = 32; s > 0; s >>= 1) dNmax = fmax(dNmax, __shfl_xor(dNmax, s, 64));
 
     // ---- tolerances (DESIGN.md "error control") ----
-    const double rtol = fmax(fmin(tune.rtol_scale * ds.rtol, tune.rtol_cap), tune.rtol_floor);
+    double rtol_ = fmax(fmin(tune.rtol_scale * ds.rtol, tune.rtol_cap), tune.rtol_floor);
+    // TRTS is linear in the carrier density: its 4-decade window spans twice the e-folds of a
+    // high-injection PL trace, and the relative error of a monotone decay accumulates per e-fold
+    if (meas == MTRPL_MEAS_TRTS) rtol_ *= tune.trts_rtol_factor;
+    // SRH with tauP >> tauN (p-type): the decay rate rises from 1/(tauN+tauP) at high injection to 1/tauN
+    // at low injection, and a relative error made before that transition is amplified by the ratio of the
+    // two rates (d ln(dN/N)/dt = -r'(N) N).  The local tolerance is tightened by that a-priori factor.
+    if (tune.amp_ref > 0.0) rtol_ /= fmax(1.0, (1.0 + p.tp / p.tn) / tune.amp_ref);
+    rtol_ = fmax(rtol_, tune.rtol_floor);
+    const double rtol = rtol_;
     const double atol = rtol * tune.atol_rel * dNmax;
     // the field is a fast slaved variable (dielectric relaxation): its local error is damped, not
     // accumulated, so it gets a looser relative weight than the densities (DESIGN.md "error control")
@@ -497,4 +519,8 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
     }
 }
 
+#endif  // !MTRPL_FP32_PASS
+
 }  // namespace mtrpl
+
+#endif  // MTRPL_SOLVE_KERNEL_HPP

@@ -2,7 +2,13 @@
 // per solve (nx <= 128*W), std or traps model.  Same algorithm and the same
 // reference mapping as solve_kernel.hpp (forward_solver.py:41-203); the device
 // functions are in solver_block.hpp.
-#pragma once
+// (no #pragma once: mtrpl_fp32_pass.hpp compiles this file a second time with `double` read as `float`)
+#if (!defined(MTRPL_FP32_PASS) && !defined(MTRPL_SOLVE_KERNEL_BLK_HPP_F64)) || (defined(MTRPL_FP32_PASS) && !defined(MTRPL_SOLVE_KERNEL_BLK_HPP_F32))
+#ifdef MTRPL_FP32_PASS
+#define MTRPL_SOLVE_KERNEL_BLK_HPP_F32
+#else
+#define MTRPL_SOLVE_KERNEL_BLK_HPP_F64
+#endif
 #include "solve_kernel.hpp"
 #include "solver_block.hpp"
 
@@ -10,9 +16,9 @@ namespace mtrpl {
 
 template <int W, bool TRAPS, bool GBLK>
 __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_desc *__restrict__ descs,
-                                                           const double *__restrict__ ini,
-                                                           const double *__restrict__ tsteps,
-                                                           double *__restrict__ out, int32_t *__restrict__ status,
+                                                           const f64 *__restrict__ ini,
+                                                           const f64 *__restrict__ tsteps,
+                                                           f64 *__restrict__ out, int32_t *__restrict__ status,
                                                            int32_t *__restrict__ stats, int64_t B, SolveTuning tune,
                                                            double2 *__restrict__ gblk)
 {
@@ -36,8 +42,8 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
     const int L = ds.nx, nt = ds.nt, meas = ds.meas;
     const double dx = ds.thickness / (double)L;  // sim_utils.py:265
     const Par p = make_par(ds.par, dx);
-    const double *ts = tsteps + ds.t_off;
-    double *o = out + ds.out_off;
+    const f64 *ts = tsteps + ds.t_off;
+    f64 *o = out + ds.out_off;
     const double sig_scale = (meas == MTRPL_MEAS_TRPL) ? 1e23 : 1e9;  // forward_solver.py:189,:197
     const double min_y = ds.min_y;
     const double hmax = tune.honor_hmax ? ds.hmax : 1e300;
@@ -124,7 +130,16 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
     };
 
     // ---- tolerances (DESIGN.md "error control") ----
-    const double rtol = fmax(fmin(tune.rtol_scale * ds.rtol, tune.rtol_cap), tune.rtol_floor);
+    double rtol_ = fmax(fmin(tune.rtol_scale * ds.rtol, tune.rtol_cap), tune.rtol_floor);
+    // TRTS is linear in the carrier density: its 4-decade window spans twice the e-folds of a
+    // high-injection PL trace, and the relative error of a monotone decay accumulates per e-fold
+    if (meas == MTRPL_MEAS_TRTS) rtol_ *= tune.trts_rtol_factor;
+    // SRH with tauP >> tauN (p-type): the decay rate rises from 1/(tauN+tauP) at high injection to 1/tauN
+    // at low injection, and a relative error made before that transition is amplified by the ratio of the
+    // two rates (d ln(dN/N)/dt = -r'(N) N).  The local tolerance is tightened by that a-priori factor.
+    if (tune.amp_ref > 0.0) rtol_ /= fmax(1.0, (1.0 + p.tp / p.tn) / tune.amp_ref);
+    rtol_ = fmax(rtol_, tune.rtol_floor);
+    const double rtol = rtol_;
     const double atol = rtol * tune.atol_rel * dNmax;
     // the field is a fast slaved variable (dielectric relaxation): its local error is damped, not
     // accumulated, so it gets a looser relative weight than the densities (DESIGN.md "error control")
@@ -360,3 +375,5 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
 }
 
 }  // namespace mtrpl
+
+#endif  // MTRPL_SOLVE_KERNEL_BLK_HPP

@@ -9,7 +9,13 @@
 // one s_barrier per exchange.  For the traps model the trapped density N_trap
 // couples only to the N of its own node, so it is eliminated per node exactly like
 // E is per edge and the Newton matrix stays 2x2 block tridiagonal.
-#pragma once
+// (no #pragma once: mtrpl_fp32_pass.hpp compiles this file a second time with `double` read as `float`)
+#if (!defined(MTRPL_FP32_PASS) && !defined(MTRPL_SOLVER_BLOCK_HPP_F64)) || (defined(MTRPL_FP32_PASS) && !defined(MTRPL_SOLVER_BLOCK_HPP_F32))
+#ifdef MTRPL_FP32_PASS
+#define MTRPL_SOLVER_BLOCK_HPP_F32
+#else
+#define MTRPL_SOLVER_BLOCK_HPP_F64
+#endif
 #include "solver_device.hpp"
 
 namespace mtrpl {
@@ -372,3 +378,5 @@ __device__ inline void team_apply(Team<W> &tm, const TeamFactors<W, TRAPS> &F, c
 }
 
 }  // namespace mtrpl
+
+#endif  // MTRPL_SOLVER_BLOCK_HPP

@@ -22,11 +22,21 @@
 //     ds_bpermute; one wave per workgroup, so no barriers); all 17 elimination
 //     blocks per lane are kept in this wave's 34 KB LDS slab as 16-byte rows, so
 //     each further Newton iteration is a cheap re-solve.
-#pragma once
+// (no #pragma once: mtrpl_fp32_pass.hpp compiles this file a second time with `double` read as `float`)
+#if (!defined(MTRPL_FP32_PASS) && !defined(MTRPL_SOLVER_DEVICE_HPP_F64)) || (defined(MTRPL_FP32_PASS) && !defined(MTRPL_SOLVER_DEVICE_HPP_F32))
+#ifdef MTRPL_FP32_PASS
+#define MTRPL_SOLVER_DEVICE_HPP_F32
+#else
+#define MTRPL_SOLVER_DEVICE_HPP_F64
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/metrotrpl_amd.h"
+
+#ifndef MTRPL_FP32_PASS
+typedef double f64;  // memory that is fp64 in BOTH passes: descriptors, sample times, output samples
+#endif
 
 namespace mtrpl {
 
@@ -40,7 +50,7 @@ struct Par {
     double dx, idx, DnT, DpT, n0p0;  // idx = 1/dx
 };
 
-__device__ inline Par make_par(const double *p, double dx)
+__device__ inline Par make_par(const f64 *p, double dx)
 {
     Par q;
     q.n0 = p[MTRPL_P_N0]; q.p0 = p[MTRPL_P_P0]; q.mun = p[MTRPL_P_MU_N]; q.mup = p[MTRPL_P_MU_P];
@@ -62,10 +72,10 @@ __device__ inline double shf(double v, int src) { return __shfl(v, src, 64); }
 __device__ inline double uniform(double v)
 {
     // value is identical in all lanes: move it to scalar registers
-    union { double d; int i[2]; } u;
+    union { double d; int i[sizeof(double) / 4]; } u;
     u.d = v;
-    u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
-    u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+#pragma unroll
+    for (unsigned k = 0; k < sizeof(double) / 4; ++k) u.i[k] = __builtin_amdgcn_readfirstlane(u.i[k]);
     return u.d;
 }
 
@@ -73,10 +83,11 @@ __device__ inline double uniform(double v)
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
 __device__ inline double dpp0(double v)
 {
-    union { double d; int i[2]; } u, r;
+    union { double d; int i[sizeof(double) / 4]; } u, r;
     u.d = v;
-    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, ROW_MASK, BANK_MASK, false);
-    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, ROW_MASK, BANK_MASK, false);
+#pragma unroll
+    for (unsigned k = 0; k < sizeof(double) / 4; ++k)
+        r.i[k] = __builtin_amdgcn_update_dpp(0, u.i[k], CTRL, ROW_MASK, BANK_MASK, false);
     return r.d;
 }
 
@@ -97,10 +108,10 @@ __device__ inline double wave_sum(double v)
     v += dpp0<0x118, 0xf, 0xc>(v);   // row_shr:8, banks 2-3
     v += dpp0<0x142, 0xa>(v);        // row_bcast:15 -> rows 1,3
     v += dpp0<0x143, 0xc>(v);        // row_bcast:31 -> rows 2,3
-    union { double d; int i[2]; } u;
+    union { double d; int i[sizeof(double) / 4]; } u;
     u.d = v;
-    u.i[0] = __builtin_amdgcn_readlane(u.i[0], 63);
-    u.i[1] = __builtin_amdgcn_readlane(u.i[1], 63);
+#pragma unroll
+    for (unsigned k = 0; k < sizeof(double) / 4; ++k) u.i[k] = __builtin_amdgcn_readlane(u.i[k], 63);
     return u.d;
 }
 
@@ -116,6 +127,10 @@ __device__ inline double inv_root(double x, int k)
 // operands here are always normal, finite and non-zero)
 __device__ inline double frcp(double x)
 {
+#ifdef MTRPL_FP32_PASS
+    float q = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, q, 1.0f), q, q);
+#endif
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
     r = fma(fma(-x, r, 1.0), r, r);
@@ -418,3 +433,5 @@ __device__ inline double ndf_alpha(int k) { return (1.0 - ndf_kappa(k)) * ndf_ga
 __device__ inline double ndf_errc(int k) { return ndf_kappa(k) * ndf_gamma(k) + 1.0 / (double)(k + 1); }
 
 }  // namespace mtrpl
+
+#endif  // MTRPL_SOLVER_DEVICE_HPP

@@ -118,3 +118,16 @@ def pt_ensemble(n_chains, nx=128, rng=None):
     return dict(states=st, chain_states=states, iniPar=ini, thickness=thick, nx=nx,
                 tSteps=default_times(), hmax=4.0, meas="TRPL", model="std", ini_mode="fluence",
                 n_chains=n_chains, n_meas=n_meas, temperatures=ladder(n_chains))
+
+
+def config5(n_states=16, nx=512):
+    """BASELINE.json configs[4] / SURVEY.md 8d config 5: nx=512 drift-diffusion on a thick (2000 nm)
+    and a thin (311 nm) film, TRPL and TRTS alternating: every state of the seeded config-2 stream
+    is simulated as (2000 nm, TRPL), (2000 nm, TRTS), (311 nm, TRPL), (311 nm, TRTS)."""
+    states, flu = draw_states(n_states)
+    st = np.repeat(states, 4, axis=0)
+    ini = np.stack([np.repeat(flu, 4), np.full(4 * n_states, 6e4), np.ones(4 * n_states)], axis=1)
+    thick = np.tile([2000.0, 2000.0, 311.0, 311.0], n_states)
+    meas = ["TRPL", "TRTS", "TRPL", "TRTS"] * n_states
+    return dict(states=st, iniPar=ini, nx=nx, thickness=thick, tSteps=default_times(), hmax=4.0, meas=meas,
+                model="std", ini_mode="fluence", sigma={"TRPL": 1.0, "TRTS": 10.0})

@@ -206,3 +206,23 @@ def test_oracle_cross_check_random_draws():
         worst = max(worst, err)
         assert err <= REL_TOL, (k, err, stats[j])
     print("worst:", worst, "mean steps:", stats[:, 0].mean())
+
+
+def test_hard_cases_tauP_much_larger_than_tauN():
+    """The worst-conditioned census draws (tests/golden/make_hard_cases.py): (tauN+tauP)/tauN up to 91
+    amplifies every relative error made before the high-/low-injection transition.  TRPL and TRTS,
+    thick and thin films, all within the 1e-6 gate over the 4-decade window."""
+    from metrotrpl_amd import batch
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "hard_cases.npz"))
+    idx = {n: i for i, n in enumerate(str(z["names"]).split(","))}
+    sig, status, stats = batch.solve_batch(z["states"], idx, z["units"], z["iniPar"], z["thickness"], 128, z["tSteps"],
+                                           meas=[str(m) for m in z["meas"]], return_stats=True)
+    assert np.all(status == 0)
+    worst = 0.0
+    for k in range(len(sig)):
+        ref = z["sig"][k]
+        m = np.abs(ref) >= 1e-4 * abs(ref[0])
+        err = np.max(np.abs(sig[k][m] - ref[m]) / np.abs(ref[m]))
+        worst = max(worst, err)
+        assert err <= 1e-6, (k, str(z["meas"][k]), err)
+    print(f"hard cases: worst {worst:.2e}, steps {stats[:, 0].min()}..{stats[:, 0].max()}")

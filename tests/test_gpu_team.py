@@ -127,3 +127,36 @@ def test_team_kernel_w1_golden(gold, conv):
         ctx.set_option("kernel_variant", 0)
     print("team W=1 worst:", worst)
     assert worst <= REL_TOL
+
+
+def test_fp32_build_of_the_team_kernel(gold):
+    """configs[4] "fp32 vs fp64": the fp32 build (option precision=32) integrates the nx=512 goldens and
+    a nx=128 case, lands within fp32-level error of the reference's tight traces -- and nowhere near the
+    1e-6 gate, which is why fp64 is the product (tools/config5_sweep.py has the full sweep)."""
+    from metrotrpl_amd import _lib as L
+    ctx = L.default_context()
+    saved = {k: ctx.get_option(k) for k in ("rtol_cap", "rtol_floor", "max_steps", "atol_rel")}
+    try:
+        ctx.set_option("precision", 32)
+        assert ctx.get_option("precision") == 32
+        ctx.set_option("rtol_cap", 1e-4)
+        ctx.set_option("rtol_floor", 1e-4)
+        ctx.set_option("atol_rel", 1e-2)  # fp32 needs the looser absolute floor: Newton stalls on rounding noise otherwise
+        ctx.set_option("max_steps", 100000)
+        for key in ("cfg5_thick_pl__tight", "cfg5_thin_trts__tight", "cfg2_0__tight"):
+            sig, stats = _run(gold, key)
+            ref = gold[key + "__sig"]
+            m = np.abs(ref) >= 1e-2 * np.abs(ref[0])  # first two decades
+            err = np.max(np.abs(sig[m] - ref[m]) / np.abs(ref[m]))
+            print(f"fp32 {key}: rel={err:.2e} steps={stats[0]}")
+            assert 2e-6 < err < 2e-2, (key, err)
+        with pytest.raises(NotImplementedError):
+            _run(gold, "traps_thick__tight")
+        with pytest.raises(ValueError):
+            ctx.set_option("precision", 16)
+    finally:
+        ctx.set_option("precision", 64)
+        for k, v in saved.items():
+            ctx.set_option(k, v)
+    sig, _ = _run(gold, "cfg5_thick_pl__tight")
+    assert _relerr(sig, gold["cfg5_thick_pl__tight__sig"]) <= REL_TOL  # fp64 path untouched

@@ -9,7 +9,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from metrotrpl_amd import workloads as W, batch, _lib as L
-z = np.load(os.path.join(ROOT, "tools", "_cache", "census_refs.npz"))
+MEAS = os.environ.get("CENSUS_MEAS", "TRPL")
+z = np.load(os.path.join(ROOT, "tools", "_cache", "census_refs.npz" if MEAS == "TRPL" else f"census_refs_{MEAS.lower()}.npz"))
 N, NCH = int(z["n"]), int(z["nch"])
 c = W.config2(N); e = W.pt_ensemble(NCH); c2 = W.config2(1024)
 ix, un = W.indexes(), W.units()
@@ -31,11 +32,11 @@ def errs_of(sig, refs):
 for combo in itertools.product(*vals):
     for k, v in zip(keys, combo):
         if k == "rtol_cap":
-            ctx.set_option("rtol_floor", min(v, 1.5e-9))
+            ctx.set_option("rtol_floor", min(v, ctx.get_option("rtol_floor")))
         ctx.set_option(k, v)
-    s1, st1, stat1 = batch.solve_batch(c["states"], ix, un, c["iniPar"], c["thickness"], c["nx"], c["tSteps"], return_stats=True)
+    s1, st1, stat1 = batch.solve_batch(c["states"], ix, un, c["iniPar"], c["thickness"], c["nx"], c["tSteps"], meas=MEAS, return_stats=True)
     e1 = errs_of(s1, z["cfg2"])
-    s2, st2, stat2 = batch.solve_batch(e["states"], ix, un, e["iniPar"], e["thickness"], 128, e["tSteps"], return_stats=True)
+    s2, st2, stat2 = batch.solve_batch(e["states"], ix, un, e["iniPar"], e["thickness"], 128, e["tSteps"], meas=MEAS, return_stats=True)
     e2 = errs_of(s2, z["pt"])
     thin = e["thickness"] < 1000
     batch.solve_batch(c2["states"], ix, un, c2["iniPar"], c2["thickness"], 128, c2["tSteps"])
