@@ -102,6 +102,10 @@ def main():
     ap.add_argument("--workload", default="batch", choices=["batch", "pt"])
     ap.add_argument("--chains", type=int, default=512, help="--workload pt: total PT chains (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="experiment: issue successive steps round-robin on this many HIP streams, so that the next "
+                         "batch fills SIMDs freed by the early finishers of the previous one (default 1: back-to-back "
+                         "launches on one stream, the reported configuration)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="integrator option for experiments (mtrpl_set_option); reported in config.options")
     a = ap.parse_args()
@@ -161,15 +165,19 @@ def main():
     d_descs = torch.from_numpy(descs.view(np.uint8).reshape(-1)).to(dev)
     d_ini = torch.from_numpy(ini).to(dev)
     d_t = torch.from_numpy(t_host).to(dev)
-    d_out = torch.zeros(B * nt, dtype=torch.float64, device=dev)
-    d_status = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_stats = torch.zeros(B * 8, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream()
+    S = max(1, a.streams)
+    outs = [(torch.zeros(B * nt, dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.int32, device=dev),
+             torch.zeros(B * 8, dtype=torch.int32, device=dev)) for _ in range(S)]
+    d_out, d_status, d_stats = outs[0]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
+    stream = streams[0]
+    torch.cuda.synchronize()
 
-    def step():
+    def step(k=0):
+        o, st_, sa_ = outs[k % S]
         ctx.check(L.lib().mtrpl_solve_batch_dev(ctx.handle, B, d_descs.data_ptr(), d_ini.data_ptr(), d_t.data_ptr(),
-                                                d_out.data_ptr(), d_status.data_ptr(), d_stats.data_ptr(),
-                                                int(c["nx"]), L.MODEL[c["model"]], stream.cuda_stream))
+                                                o.data_ptr(), st_.data_ptr(), sa_.data_ptr(),
+                                                int(c["nx"]), L.MODEL[c["model"]], streams[k % S].cuda_stream))
 
     for _ in range(a.warmup):
         step()
@@ -180,9 +188,9 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     t0 = time.perf_counter()
     for k in range(a.steps):
-        ev[k][0].record(stream)
-        step()
-        ev[k][1].record(stream)
+        ev[k][0].record(streams[k % S])
+        step(k)
+        ev[k][1].record(streams[k % S])
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -218,7 +226,7 @@ def main():
                        "solves_per_gpu_per_step": B, "nx": int(c["nx"]), "nt_out": int(nt), "parallelism": f"batch-shard x{world}",
                        "all_solves_ok": ok, "mean_integrator_steps": float(stats[:, 0].mean()),
                        "mean_rhs_evals": float(stats[:, 1].mean()), "max_integrator_steps": int(stats[:, 0].max()),
-                       **({"options": a.opt} if a.opt else {})},
+                       **({"options": a.opt} if a.opt else {}), **({"streams": S} if S > 1 else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "solve_kernel_r2",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_solve": A,

@@ -190,6 +190,7 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
 {
     constexpr int R = 2, V = 6;
     const int64_t sidx = blockIdx.x;
+    const unsigned long long clk0_ = __builtin_amdgcn_s_memtime();
     if (sidx >= B) return;
     const int lane = threadIdx.x & 63;
     const mtrpl_solve_desc &ds = descs[sidx];
@@ -509,7 +510,8 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
         if (stats) {
             int32_t *s = stats + 8 * sidx;
             s[0] = n_steps; s[1] = n_rhs; s[2] = n_fac; s[3] = n_jac;
-            s[4] = n_rej; s[5] = n_nfail; s[6] = order; s[7] = 0;
+            s[4] = n_rej; s[5] = n_nfail; s[6] = order;
+            s[7] = (int32_t)((__builtin_amdgcn_s_memtime() - clk0_) >> 4);  // residency of this solve, 16-tick units of the constant-rate counter
 #ifdef MTRPL_STAMPS
             s[1] = (int)(ph_sel >> 10); s[2] = (int)(ph_pred >> 10); s[3] = (int)(ph_fac >> 10);
             s[4] = (int)(ph_newt >> 10); s[5] = (int)(ph_err >> 10); s[6] = (int)(ph_upd >> 10);

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
 {
     constexpr int R = 2, V = TRAPS ? 8 : 6, T = Team<W>::T;
     const int64_t sidx = blockIdx.x;
+    const unsigned long long clk0_ = __builtin_amdgcn_s_memtime();
     if (sidx >= B) return;
     const int lane = threadIdx.x & 63, tid = threadIdx.x;
     __shared__ double2 xbuf_lds[team_xbuf_bytes<W>() / 16];
@@ -369,7 +370,8 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
         if (stats) {
             int32_t *s = stats + 8 * sidx;
             s[0] = n_steps; s[1] = n_rhs; s[2] = n_fac; s[3] = n_jac;
-            s[4] = n_rej; s[5] = n_nfail; s[6] = order; s[7] = 0;
+            s[4] = n_rej; s[5] = n_nfail; s[6] = order;
+            s[7] = (int32_t)((__builtin_amdgcn_s_memtime() - clk0_) >> 4);  // residency of this solve, 16-tick units of the constant-rate counter
         }
     }
 }
