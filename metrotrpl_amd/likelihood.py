@@ -21,7 +21,7 @@ from . import batch
 class LikelihoodEngine:
     def __init__(self, indexes, units, lengths, nx, meas_types, times, vals, uncs, sigma, iniPar, ini_mode="fluence",
                  model="std", hmax=4.0, rtol=None, atol=None, irf_tables=None, irf_convolution=None,
-                 scale_shift=None, force_min_y=False, device=0, ctx=None, fittables=None):
+                 scale_shift=None, force_min_y=False, device=0, ctx=None, fittables=None, sort_by_cost=True):
         """times/vals/uncs: per-measurement 1-D arrays (as _times/_vals/_uncs of the
         reference's shared fields); sigma: {meas_type: model_uncertainty};
         irf_tables: {wavelength: (table [k,3], t_irf [k])} from make_I_tables;
@@ -68,6 +68,7 @@ class LikelihoodEngine:
             self.ctx.check(L.lib().mtrpl_irf_tables_upload(self.ctx.handle, len(waves), L.iptr(nk), L.dptr(tabs),
                                                            L.dptr(dts)))
             self.irf_index = [waves.index(int(w)) if w else -1 for w in irf_convolution]
+        self.sort_by_cost = bool(sort_by_cost)
         self._cap = 0
 
     def _ensure(self, n_solves, nT):
@@ -118,6 +119,14 @@ class LikelihoodEngine:
         ld["force_min_y"] = int(self.force_min_y)
         ld["scale_shift"] = shift
         ld["sigma"] = np.tile(self.sigma, Cn)
+        if self.sort_by_cost and d.shape[0] > 1024:
+            # more solves than SIMDs: the hardware hands out workgroups in index order, so put the
+            # expensive ones first (longest-processing-time-first): the tightened-tolerance solves
+            # (tauP >> tauN, see DESIGN.md "error control") and the thin, fast-decaying films.
+            # Only the solve descriptors move; outputs keep their places (out_off), the likelihood
+            # descriptors and the ll table keep chain-major order.
+            tn, tp = st[:, self.indexes["tauN"]], st[:, self.indexes["tauP"]]
+            d = d[np.argsort(-(1.0 + tp / tn), kind="stable")]
         return d, ini_arr, ld
 
     def upload(self, states):

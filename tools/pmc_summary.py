@@ -1,0 +1,39 @@
+"""Summarise rocprofv3 --pmc counter CSVs (one directory per pass) for one kernel into
+profiles/hbm_traffic.json (dev tool).
+    python tools/pmc_summary.py <kernel-substring> <out.json> <pass-dir> [<pass-dir> ...]"""
+import csv
+import glob
+import json
+import os
+import sys
+
+kern, out = sys.argv[1], sys.argv[2]
+vals = {}
+for d in sys.argv[3:]:
+    for fn in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        acc = {}
+        for row in csv.DictReader(open(fn)):
+            if kern in row["Kernel_Name"]:
+                acc.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
+                acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+        for c, per in acc.items():
+            v = list(per.values())
+            vals[c] = sum(v) / len(v)  # average per launch
+fetch, write = vals.get("FETCH_SIZE"), vals.get("WRITE_SIZE")
+res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, --kernel-trace only) on "
+                 "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline`; kernel " + kern + ", average per launch (1024 solves)",
+       "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
+       "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE reports 1/2 of a wide coalesced read on gfx950 -> doubled; "
+                     "WRITE_SIZE exact; both in KiB.  Reads here are small descriptor/time-grid loads, so the factor is an upper bound.",
+       "solve_kernel_bytes_per_launch": (2 * fetch + write) * 1024 if fetch is not None and write is not None else None,
+       "expected_compulsory_bytes_per_launch": 1024 * (280 + 8 * 1001 + 4 + 32) + 8 * 1001,
+       "sq_counters_per_launch": {k: v for k, v in vals.items() if k.startswith("SQ_")}}
+sq = res["sq_counters_per_launch"]
+if "SQ_WAVES" in sq:
+    w = sq["SQ_WAVES"]
+    res["derived"] = {"valu_insts_per_solve": sq.get("SQ_INSTS_VALU", 0) / w, "salu_insts_per_solve": sq.get("SQ_INSTS_SALU", 0) / w,
+                      "lds_insts_per_solve": sq.get("SQ_INSTS_LDS", 0) / w,
+                      "valu_active_fraction_of_wave_cycles": sq.get("SQ_ACTIVE_INST_VALU", 0) / sq["SQ_WAVE_CYCLES"] if sq.get("SQ_WAVE_CYCLES") else None,
+                      "wave_cycles_per_solve(quad-cycles*4)": 4 * sq.get("SQ_WAVE_CYCLES", 0) / w}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))
