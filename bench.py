@@ -207,6 +207,24 @@ def main():
     sig = d_out.cpu().numpy().reshape(B, nt)
     ok = bool(np.all(status == 0) and np.all(np.isfinite(sig)))
 
+    # measured HBM stream rate of this device (read + write of a 1 GiB buffer), next to the nominal peak
+    copy_gbs = None
+    if rank == 0:
+        try:
+            src = torch.empty(1 << 27, dtype=torch.float64, device=dev)  # 1 GiB
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 5 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del src, dst
+        except Exception:
+            copy_gbs = None
     if rank == 0:
         A = algorithmic_bytes_per_solve(c["nx"], nt)
         achieved = A * B / (kern_ms * 1e-3) / 1e9
@@ -230,6 +248,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "solve_kernel_r2",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_solve": A,
+                         "measured_stream_copy": copy_gbs,
                          "note": "state-streaming model of SURVEY.md 8d; the solve state is register-resident by "
                                  "design, so HBM is not the limiter (see DESIGN.md)"},
         }

@@ -178,3 +178,20 @@ def test_metro_checkpoint_resume_is_the_same_walk(tmp_path):
     np.testing.assert_array_equal(resumed.H.states[:, :, :6], full.H.states[:, :, :6])
     assert resumed.H.states.shape == full.H.states.shape
     assert full.H.accept.sum() > 0
+
+
+def test_load_a_pickle_written_by_the_reference():
+    """tests/golden/ref_ensemble.pik was written by the reference's own Ensemble.checkpoint
+    (make_pickle_golden.py); the reference is not importable here, the loader maps its classes."""
+    assert "sim_utils" not in sys.modules or not hasattr(sys.modules["sim_utils"], "Covariance")
+    E = S.load_pickle(os.path.join(os.path.dirname(__file__), "golden", "ref_ensemble.pik"))
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mcmc.npz"))
+    assert isinstance(E, S.Ensemble) and isinstance(E.H, S.History)
+    np.testing.assert_array_equal(E.H.states, z["pt__states"])
+    np.testing.assert_array_equal(E.H.swap_accept, z["pt__swap_accept"])
+    assert E.latest_iter == 12 and E.ensemble_fields["_n_chains"] == 3
+    assert E.H.mean__s1.shape == (3, 24) and E.ensemble_fields["names"][-1] == "_s1"
+    assert E.random_state["bit_generator"] == "PCG64"
+    # and it can be continued: extend the record and re-checkpoint under the reference's class path
+    E.H.extend(30)
+    assert E.H.states.shape == (3, 14, 30)
