@@ -40,6 +40,7 @@ struct SolveTuning {
     int honor_hmax;     // 1: desc.hmax caps the step (the reference's max_step); 0: error control alone
     double trts_rtol_factor;  // internal rtol of TRTS solves = this x that of TRPL solves (not below rtol_floor)
     double amp_ref;           // > 0: internal rtol /= max(1, (1 + tauP/tauN) / amp_ref); 0: off
+    int fresh_jac;            // 1: every refactorisation re-evaluates the Jacobian at the current predictor
 };
 
 // RMS norm over the 3nx+1 ODE components; v is already divided by the weights.
@@ -370,6 +371,14 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
             while (!converged) {
                 if (!have_fac) {
                     MTRPL_STAMP(ph_newt);
+                    if (tune.fresh_jac && !jac_current) {
+                        // the analytic Jacobian is evaluated inside the factorisation anyway: take it at
+                        // the current predictor instead of the point of the last convergence failure
+#pragma unroll
+                        for (int v = 0; v < V; ++v) yJ[v] = yp[v];
+                        n_jac++;
+                        jac_current = true;
+                    }
                     build_factors(p, yJ, c, lane, L, F);
                     have_fac = true;
                     n_fac++;

@@ -237,6 +237,14 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
             int n_iter = 0;
             while (!converged) {
                 if (!have_fac) {
+                    if (tune.fresh_jac && !jac_current) {
+                        // the analytic Jacobian is evaluated inside the factorisation anyway: take it at
+                        // the current predictor instead of the point of the last convergence failure
+#pragma unroll
+                        for (int v = 0; v < V; ++v) yJ[v] = yp[v];
+                        n_jac++;
+                        jac_current = true;
+                    }
                     team_build<W, TRAPS>(tm, p, yJ, c, L, F);
                     have_fac = true;
                     n_fac++;
