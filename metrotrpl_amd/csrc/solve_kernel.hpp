@@ -43,6 +43,35 @@ struct SolveTuning {
     int fresh_jac;            // 1: every refactorisation re-evaluates the Jacobian at the current predictor
 };
 
+// Norms only steer step-size, order and Newton decisions: the f32 hardware square root (1 ulp of
+// f32) is plenty and replaces the fp64 v_sqrt + refinement sequence on the critical path.
+__device__ inline double norm_sqrt(double x) { return (double)__builtin_amdgcn_sqrtf((float)x); }
+
+// 1/x to f32 accuracy for quantities that only steer the controller (error weights, contraction rates)
+__device__ inline double ctl_rcp(double x) { return (double)__builtin_amdgcn_rcpf((float)x); }
+
+// NDF constants of order K as compile-time values (Shampine & Reichelt 1997): inside
+// MTRPL_ORDER_SWITCH they cost nothing, where the run-time select chains of ndf_kappa/ndf_gamma and the
+// fp64 division in ndf_errc sat on the scalar critical path of every step.
+template <int K>
+struct NdfC {
+    static constexpr double kp[7] = {0.0, -0.1850, -1.0 / 9.0, -0.0823, -0.0415, 0.0, 0.0};
+    static constexpr double gm[7] = {0.0, 1.0, 1.5, 1.5 + 1.0 / 3.0, 1.5 + 1.0 / 3.0 + 0.25, 1.5 + 1.0 / 3.0 + 0.25 + 0.2, 0.0};
+    static constexpr double alpha = (1.0 - kp[K]) * gm[K];
+    static constexpr double ialpha = 1.0 / alpha;
+    static constexpr double errc = kp[K] * gm[K] + 1.0 / (double)(K + 1);
+    static constexpr double errc_lo = (K > 1) ? kp[K > 1 ? K - 1 : 1] * gm[K > 1 ? K - 1 : 1] + 1.0 / (double)K : 0.0;
+    static constexpr double errc_hi = (K < 5) ? kp[K + 1] * gm[K + 1] + 1.0 / (double)(K + 2) : 0.0;
+    static constexpr float nik0 = -1.0f / (float)K, nik1 = -1.0f / (float)(K + 1), nik2 = -1.0f / (float)(K + 2);
+};
+
+// x^e (e = -1/k as a compile-time constant): f32 hardware log2 / exp2
+__device__ inline double pow_neg_inv(double x, float e)
+{
+    const float xf = (float)fmin(fmax(x, 1e-30), 1e30);
+    return (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xf) * e);
+}
+
 // RMS norm over the 3nx+1 ODE components; v is already divided by the weights.
 template <int V>
 __device__ inline double wnorm(const double (&v)[V], double inv_S)
@@ -50,7 +79,7 @@ __device__ inline double wnorm(const double (&v)[V], double inv_S)
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < V; ++k) s += v[k] * v[k];
-    return uniform(sqrt(wave_sum(s) * inv_S));
+    return uniform(norm_sqrt(wave_sum(s) * inv_S));
 }
 
 // D[0..order] <- (R(factor) U)^T D[0..order]  (rescale the backward differences
@@ -356,13 +385,13 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
             // predictor
             MTRPL_STAMP(ph_err);
             double yp[V], psi[V];
-            MTRPL_ORDER_SWITCH(order, (ndf_predict<K, V>(D, yp, psi)))
-            const double ialpha = frcp(ndf_alpha(order));
+            double ialpha = 1.0, ec = 1.0;
+            MTRPL_ORDER_SWITCH(order, (ndf_predict<K, V>(D, yp, psi), ialpha = NdfC<K>::ialpha, ec = NdfC<K>::errc))
             const double c = h * ialpha;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 psi[v] *= ialpha;
-                isc[v] = frcp(atol + rtol_of(v) * fabs(yp[v]));
+                isc[v] = ctl_rcp(atol + rtol_of(v) * fabs(yp[v]));
             }
             // simplified Newton
             MTRPL_STAMP(ph_pred);
@@ -406,10 +435,10 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
                     // is carried over (Brown, Byrne & Hindmarsh 1989, VODE "crate")
                     double rate = rate_prev;
                     if (k > 0) {
-                        rate = dn * frcp(dn_old);
+                        rate = dn * ctl_rcp(dn_old);
                         double rp = rate;  // rate^(4-k)
                         for (int q = 1; q < 4 - k; ++q) rp *= rate;
-                        if (rate >= 1.0 || rp * frcp(1.0 - rate) * dn > newton_tol) break;
+                        if (rate >= 1.0 || rp * dn > newton_tol * (1.0 - rate)) break;
                         // first measurement with new factors: take it (x rate_first_safety) instead
                         // of smoothing down from 1 over several two-iteration steps
                         rate_prev = (rate_prev >= 1.0 && tune.rate_first_safety > 0.0)
@@ -420,7 +449,7 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
 #pragma unroll
                     for (int v = 0; v < V; ++v) { yn[v] += dy[v]; d[v] += dy[v]; }
                     const bool rate_ok = (k > 0) || (rate_prev < 0.9 && rate_age < tune.rate_max_age);
-                    if (dn == 0.0 || (rate_ok && rate < 1.0 && rate * frcp(1.0 - rate) * dn < newton_tol)) { converged = true; break; }
+                    if (dn == 0.0 || (rate_ok && rate < 1.0 && rate * dn < newton_tol * (1.0 - rate))) { converged = true; break; }
                     dn_old = dn;
                 }
                 if (converged && n_iter == 1) rate_age++;
@@ -444,7 +473,6 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
             MTRPL_STAMP(ph_newt);
             // 0.9 * (2*4 + 1) / (2*4 + n_iter), n_iter = 1..4
             safety = (n_iter == 1) ? 0.9 : ((n_iter == 2) ? 0.81 : ((n_iter == 3) ? 8.1 / 11.0 : 0.675));
-            const double ec = ndf_errc(order);
 #pragma unroll
             for (int v = 0; v < V; ++v) w[v] = ec * d[v] * isc[v];
             err_norm = wnorm<V>(w, inv_S);
@@ -482,18 +510,21 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
         if (n_equal < order + 1) continue;
         // order / step-size selection
         double sm = 0.0, sp = 0.0;
-        MTRPL_ORDER_SWITCH(order, (ndf_sel<K, V>(D, isc, sm, sp)))
-        const double em = (order > 1) ? ndf_errc(order - 1) * uniform(sqrt(wave_sum(sm) * inv_S)) : 1e300;
-        const double ep = (order < 5) ? ndf_errc(order + 1) * uniform(sqrt(wave_sum(sp) * inv_S)) : 1e300;
-        const double fm = (order > 1) ? inv_root(em, order) : 0.0;
-        const double f0 = inv_root(err_norm, order + 1);
-        const double fp = (order < 5) ? inv_root(ep, order + 2) : 0.0;
+        double ec_lo = 0.0, ec_hi = 0.0;
+        float e0 = -0.5f, e1 = -0.5f, e2 = -0.5f;
+        MTRPL_ORDER_SWITCH(order, (ndf_sel<K, V>(D, isc, sm, sp), ec_lo = NdfC<K>::errc_lo, ec_hi = NdfC<K>::errc_hi,
+                                   e0 = NdfC<K>::nik0, e1 = NdfC<K>::nik1, e2 = NdfC<K>::nik2))
+        const double em = (order > 1) ? ec_lo * uniform(norm_sqrt(wave_sum(sm) * inv_S)) : 1e300;
+        const double ep = (order < 5) ? ec_hi * uniform(norm_sqrt(wave_sum(sp) * inv_S)) : 1e300;
+        const double fm = (order > 1) ? pow_neg_inv(em, e0) : 0.0;
+        const double f0 = pow_neg_inv(err_norm, e1);
+        const double fp = (order < 5) ? pow_neg_inv(ep, e2) : 0.0;
         int dorder = 0;
         double fbest = f0;
         if (fm > fbest) { fbest = fm; dorder = -1; }
         if (fp > fbest) { fbest = fp; dorder = 1; }
         double fac = fmin(10.0, safety * fbest);
-        if (h * fac > hmax) fac = hmax / h;
+        if (h * fac > hmax) fac = hmax * ih;
         if (dorder == 0 && fac >= 0.9 && fac < 1.2) {
             n_equal = order - 2;  // keep h and the factors; test again three steps on
             continue;

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < V; ++k) s += v[k] * v[k];
-        return sqrt(team_sum<W>(tm, s) * inv_S_);
+        return norm_sqrt(team_sum<W>(tm, s) * inv_S_);
     };
     const mtrpl_solve_desc &ds = descs[sidx];
     const int L = ds.nx, nt = ds.nt, meas = ds.meas;
@@ -224,13 +224,13 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
             if (++attempts > 60 || !(h > 1e-13 * fmax(t, 1e-3))) { st = MTRPL_SOLVE_STOPPED_EARLY; break; }
             // predictor
             double yp[V], psi[V];
-            MTRPL_ORDER_SWITCH(order, (ndf_predict<K, V>(D, yp, psi)))
-            const double ialpha = frcp(ndf_alpha(order));
+            double ialpha = 1.0, ec = 1.0;
+            MTRPL_ORDER_SWITCH(order, (ndf_predict<K, V>(D, yp, psi), ialpha = NdfC<K>::ialpha, ec = NdfC<K>::errc))
             const double c = h * ialpha;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 psi[v] *= ialpha;
-                isc[v] = frcp(atol + rtol_of(v) * fabs(yp[v]));
+                isc[v] = ctl_rcp(atol + rtol_of(v) * fabs(yp[v]));
             }
             // simplified Newton
             bool converged = false;
@@ -271,10 +271,10 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
                     // is carried over (Brown, Byrne & Hindmarsh 1989, VODE "crate")
                     double rate = rate_prev;
                     if (k > 0) {
-                        rate = dn * frcp(dn_old);
+                        rate = dn * ctl_rcp(dn_old);
                         double rp = rate;  // rate^(4-k)
                         for (int q = 1; q < 4 - k; ++q) rp *= rate;
-                        if (rate >= 1.0 || rp * frcp(1.0 - rate) * dn > newton_tol) break;
+                        if (rate >= 1.0 || rp * dn > newton_tol * (1.0 - rate)) break;
                         rate_prev = (rate_prev >= 1.0 && tune.rate_first_safety > 0.0)
                                         ? fmin(fmax(tune.rate_first_safety * rate, 1e-4), 0.9)
                                         : fmax(0.3 * rate_prev, rate);
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
 #pragma unroll
                     for (int v = 0; v < V; ++v) { yn[v] += dy[v]; d[v] += dy[v]; }
                     const bool rate_ok = (k > 0) || (rate_prev < 0.9 && rate_age < tune.rate_max_age);
-                    if (dn == 0.0 || (rate_ok && rate < 1.0 && rate * frcp(1.0 - rate) * dn < newton_tol)) { converged = true; break; }
+                    if (dn == 0.0 || (rate_ok && rate < 1.0 && rate * dn < newton_tol * (1.0 - rate))) { converged = true; break; }
                     dn_old = dn;
                 }
                 if (converged && n_iter == 1) rate_age++;
@@ -305,7 +305,6 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
                 continue;
             }
             safety = 0.9 * (2.0 * 4 + 1) / (2.0 * 4 + n_iter);
-            const double ec = ndf_errc(order);
 #pragma unroll
             for (int v = 0; v < V; ++v) w[v] = ec * d[v] * isc[v];
             err_norm = tnorm(w, inv_S);
@@ -340,10 +339,11 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
         if (n_equal < order + 1) continue;
         // order / step-size selection
         double sm = 0.0, sp = 0.0;
-        MTRPL_ORDER_SWITCH(order, (ndf_sel<K, V>(D, isc, sm, sp)))
+        double ec_lo = 0.0, ec_hi = 0.0;
+        MTRPL_ORDER_SWITCH(order, (ndf_sel<K, V>(D, isc, sm, sp), ec_lo = NdfC<K>::errc_lo, ec_hi = NdfC<K>::errc_hi))
         team_sum2<W>(tm, sm, sp);
-        const double em = (order > 1) ? ndf_errc(order - 1) * sqrt(sm * inv_S) : 1e300;
-        const double ep = (order < 5) ? ndf_errc(order + 1) * sqrt(sp * inv_S) : 1e300;
+        const double em = (order > 1) ? ec_lo * norm_sqrt(sm * inv_S) : 1e300;
+        const double ep = (order < 5) ? ec_hi * norm_sqrt(sp * inv_S) : 1e300;
         const double fm = (order > 1) ? inv_root(em, order) : 0.0;
         const double f0 = inv_root(err_norm, order + 1);
         const double fp = (order < 5) ? inv_root(ep, order + 2) : 0.0;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
         if (fm > fbest) { fbest = fm; dorder = -1; }
         if (fp > fbest) { fbest = fp; dorder = 1; }
         double fac = fmin(10.0, safety * fbest);
-        if (h * fac > hmax) fac = hmax / h;
+        if (h * fac > hmax) fac = hmax * ih;
         if (dorder == 0 && fac >= 0.9 && fac < 1.2) {
             n_equal = order - 2;  // keep h and the factors; test again three steps on
             continue;
