@@ -82,6 +82,16 @@ __device__ inline double wnorm(const double (&v)[V], double inv_S)
     return uniform(norm_sqrt(wave_sum(s) * inv_S));
 }
 
+// value of lane `src` (a compile-time constant after unrolling) as a wave-uniform scalar
+__device__ inline double lane_value(double v, int src)
+{
+    union { double d; int i[sizeof(double) / 4]; } u;
+    u.d = v;
+#pragma unroll
+    for (unsigned k = 0; k < sizeof(double) / 4; ++k) u.i[k] = __builtin_amdgcn_readlane(u.i[k], src);
+    return u.d;
+}
+
 // D[0..order] <- (R(factor) U)^T D[0..order]  (rescale the backward differences
 // to a step factor*h; Shampine & Reichelt eq. for quasi-constant step size).
 // The (order+1)^2 coefficients are wave-uniform: lane 6*j+i computes RU[j][i],
@@ -92,17 +102,23 @@ __device__ inline void change_D(double (&D)[8][V], int order, double factor, int
     const int j = lane / 6, i = lane % 6;  // coefficient (j,i), lanes 0..35
     double ru = 0.0;
     if (lane < 36 && j <= order && i <= order) {
-        // R[j][m] = prod_{k=1..j} (k-1-factor*m)/k, U[m][i] = prod_{k=1..m} (k-1-i)/k ; column/row 0 special
+        // R[j][m] = prod_{k=1..j} (k-1-factor*m)/k, U[m][i] = prod_{k=1..m} (k-1-i)/k ; column/row 0 special.
+        // Fully unrolled with predicates and reciprocal constants: the run-time loop bounds and fp64
+        // divisions of the straightforward form cost ~10k cycles per call.
+        constexpr double inv[6] = {0.0, 1.0, 0.5, 1.0 / 3.0, 0.25, 0.2};
+        const double fi = (double)i;
 #pragma unroll
         for (int m = 0; m < 6; ++m) {
-            if (m <= order) {
-                double rjm = 1.0, umi = 1.0;
-                for (int k = 1; k <= j; ++k) rjm *= ((double)(k - 1) - factor * (double)m) / (double)k;
-                for (int k = 1; k <= m; ++k) umi *= ((double)(k - 1) - (double)i) / (double)k;
-                if (m == 0 && j > 0) rjm = 0.0;
-                if (i == 0 && m > 0) umi = 0.0;
-                ru += rjm * umi;
+            double rjm = 1.0, umi = 1.0;
+            const double fm_ = factor * (double)m;
+#pragma unroll
+            for (int k = 1; k < 6; ++k) {
+                rjm *= (k <= j) ? ((double)(k - 1) - fm_) * inv[k] : 1.0;
+                umi *= (k <= m) ? ((double)(k - 1) - fi) * inv[k] : 1.0;
             }
+            if (m == 0 && j > 0) rjm = 0.0;
+            if (i == 0 && m > 0) umi = 0.0;
+            ru += (m <= order) ? rjm * umi : 0.0;
         }
     }
     double Dn[6][V];
@@ -112,7 +128,7 @@ __device__ inline void change_D(double (&D)[8][V], int order, double factor, int
         for (int v = 0; v < V; ++v) Dn[ii][v] = 0.0;
 #pragma unroll
         for (int jj = 0; jj < 6; ++jj) {
-            const double cf = uniform(shf(ru, jj * 6 + ii));
+            const double cf = lane_value(ru, jj * 6 + ii);
 #pragma unroll
             for (int v = 0; v < V; ++v) Dn[ii][v] += cf * D[jj][v];
         }
