@@ -82,14 +82,26 @@ int mtrpl_ctx_create(int device, mtrpl_ctx **ctx);
 int mtrpl_ctx_destroy(mtrpl_ctx *ctx);
 const char *mtrpl_last_error(const mtrpl_ctx *ctx);
 const char *mtrpl_version(void);
-/* tunables: "rtol_scale","rtol_cap","atol_rel","max_steps"  */
+/* Integrator options.  Unknown key -> MTRPL_ERR_BAD_ARG.
+ *   rtol_scale, rtol_cap, rtol_floor  internal rtol = clamp(rtol_scale * desc.rtol, rtol_floor, rtol_cap) ...
+ *   trts_rtol_factor                  ... x this for TRTS solves ...
+ *   amp_ref                           ... / max(1, (1 + tauP/tauN) / amp_ref)   (0 = off), never below rtol_floor
+ *   atol_rel                          internal atol = rtol_int * atol_rel * max(N0, P0)
+ *   e_weight                          relative error weight of the field components (x rtol_int)
+ *   newton_tol, rate_max_age, rate_first_safety   simplified-Newton convergence control
+ *   fresh_jac                         1: Jacobian re-evaluated at every refactorisation
+ *   honor_hmax                        1: desc.hmax is the maximum step (the reference's max_step)
+ *   max_steps                         a solve that needs more stops early (status 1, tail zero-filled)
+ *   kernel_variant                    1: team kernel also for nx <= 128 (test hook)
+ *   precision                         64 (product) | 32 (fp32 build of the team kernel: precision sweep only) */
 int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value);
 int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value);
 
 /* ---- a1/a6/a7/a8/a9: batched forward solve ----------------------------- */
 /* replaces forward_solver.solve (forward_solver.py:41-203) for B calls at once.
  * stats (may be NULL): 8 int32 per solve = steps, rhs evals, factorisations,
- * jacobian refreshes, rejected steps, newton failures, final order, spare. */
+ * jacobian refreshes, rejected steps, newton failures, final order, residency of the solve on
+ * its SIMD in units of 16 shader-clock ticks. */
 int mtrpl_solve_batch(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *descs,
                       const double *ini, int64_t n_ini, const double *tsteps, int64_t n_t,
                       double *out, int64_t n_out, int32_t *status, int32_t *stats);
