@@ -147,19 +147,29 @@ __device__ inline bool argmax_better(double vb, int64_t ib, double va, int64_t i
 }
 
 // block-wide argmax of per-thread candidates (256 threads); result in sv[0], si[0]
+// first-maximum over the block (any number of full waves): wave-level butterfly, then one thread
+// combines the per-wave winners.  sv/si: >= blockDim.x/64 entries of LDS.
 __device__ inline void block_argmax(double &best, int64_t &bi, int64_t n, double *sv, int64_t *si)
 {
-    sv[threadIdx.x] = best;
-    si[threadIdx.x] = bi;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s &&
-            argmax_better(sv[threadIdx.x + s], si[threadIdx.x + s], sv[threadIdx.x], si[threadIdx.x], n)) {
-            sv[threadIdx.x] = sv[threadIdx.x + s];
-            si[threadIdx.x] = si[threadIdx.x + s];
-        }
-        __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(best, o, 64);
+        const int64_t oi = __shfl_xor((long long)bi, o, 64);
+        if (argmax_better(ov, oi, best, bi, n)) { best = ov; bi = oi; }
     }
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sv[wave] = best; si[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double b = sv[0];
+        int64_t i = si[0];
+        for (int w = 1; w < nw; ++w)
+            if (argmax_better(sv[w], si[w], b, i, n)) { b = sv[w]; i = si[w]; }
+        sv[0] = b;
+        si[0] = i;
+    }
+    __syncthreads();
     best = sv[0];
     bi = si[0];
     __syncthreads();
@@ -167,8 +177,8 @@ __device__ inline void block_argmax(double &best, int64_t &bi, int64_t n, double
 
 __global__ __launch_bounds__(256) void argmax_kernel(const double *__restrict__ h, int64_t n, int64_t *__restrict__ out)
 {
-    __shared__ double sv[256];
-    __shared__ int64_t si[256];
+    __shared__ double sv[4];
+    __shared__ int64_t si[4];
     double best = 0.0;
     int64_t bi = n;
     for (int64_t i = threadIdx.x; i < n; i += 256)
@@ -204,12 +214,15 @@ __global__ void conv_time_kernel(int64_t n_conv, int64_t n_r, double half_dt, do
 // A window of 189 taps crosses 3-4 simulation intervals, so one output costs a
 // few dozen flops instead of 567 FMAs; intervals that straddle a simulation
 // sample (and the snapped last one) are evaluated directly from the definition.
-constexpr int kLikeBlock = 256;
+constexpr int kLikeBlock = 768;   // 8 waves per trace: two blocks per CU keep 4 waves per SIMD in flight
+constexpr int kLikeWaves = kLikeBlock / 64;
+constexpr int kLikeMaxNt = 1024; // LDS budget (5 arrays of doubles + the run table)
 
 struct ConvCtx {
     const double *st, *sy, *sb;   // LDS: times, values, slopes of the simulation intervals
     const double *T;              // LDS: moment table [nk][3]
     const double *P0, *Q0, *P1;   // LDS: prefix sums [nk+1]
+    const int *jlo, *jhi;         // LDS [nt-1]: regular run of interval q = convolution indices jlo[q]..jhi[q]
     int nt, nk;
     int64_t n_r, nkk;
     double half_dt, t_end, inv_2d;
@@ -285,6 +298,87 @@ __device__ inline double conv_fast(const ConvCtx &c, int64_t k, int &qhint)
     return acc;
 }
 
+// Regular run of simulation interval q: the convolution indices j whose three resampled points
+// tau_2j, tau_2j+1, tau_2j+2 all lie inside [st[q], st[q+1]] (and j < nkk-1: the last index uses the
+// snapped end point).  jhi is non-decreasing in q whether or not the run is empty (jlo > jhi).
+__device__ inline void conv_runs(const ConvCtx &c, int q, int &jl_out, int &jh_out)
+{
+    const double a = c.st[q], b = c.st[q + 1];
+    int64_t je = (int64_t)floor(b * c.inv_2d) - 1;
+    while (resampled_time(2 * je + 4, c.n_r, c.half_dt, c.t_end) <= b) ++je;
+    while (je >= 0 && resampled_time(2 * je + 2, c.n_r, c.half_dt, c.t_end) > b) --je;
+    if (je > c.nkk - 2) je = c.nkk - 2;
+    int64_t jl = (int64_t)ceil(a * c.inv_2d);
+    if (jl < 0) jl = 0;
+    while (jl > 0 && resampled_time(2 * (jl - 1), c.n_r, c.half_dt, c.t_end) >= a) --jl;
+    while (resampled_time(2 * jl, c.n_r, c.half_dt, c.t_end) < a) ++jl;
+    jl_out = (int)jl;
+    jh_out = (int)je;
+}
+
+__device__ inline double conv_interp_near(const ConvCtx &c, double v, int qhint)
+{
+    if (!(v >= c.st[0] && v <= c.st[c.nt - 1])) return __builtin_nan("");
+    const int q = conv_segment_near(c, v, qhint);
+    return c.sb[q] * (v - c.st[q]) + c.sy[q];
+}
+
+// h[k] of laplace.py:204-210 with the run table: the same sums, in the same order and with the same
+// arithmetic as conv_fast, but the decomposition of the tap window into runs is looked up instead of
+// re-derived (floor + searches) for every output.  q (in/out): first interval with jhi[q] >= k - nk;
+// monotone in k, so a thread walking consecutive outputs advances it by amortised O(1).
+__device__ inline double conv_fast2(const ConvCtx &c, int64_t k64, int &q)
+{
+    if (k64 <= 0) return 0.0;
+    // 32-bit index arithmetic: the caller guarantees n_r < 2^31 (checked once per trace)
+    const int k = (int)k64, nr1 = (int)(c.n_r - 1);
+    auto tau = [&](int i) {  // resampled_time(i): laplace.py:68-72, last point snapped to t_end
+        double tq = (double)i * c.half_dt;
+        if (i == nr1 && tq > c.t_end) tq = c.t_end;
+        return tq;
+    };
+    const int lo = (k - c.nk > 0) ? k - c.nk : 0, hi = k - 1;
+    const int qlast = c.nt - 2;
+    while (q < qlast && c.jhi[q] < lo) ++q;
+    int qq = q;
+    double acc = 0.0;
+    int cur = lo;
+    while (cur <= hi) {
+        while (qq < qlast && c.jhi[qq] < cur) ++qq;
+        const int jl = c.jlo[qq], je = c.jhi[qq];
+        if (cur >= jl && cur <= je) {
+            const double t1 = tau(2 * cur + 1);
+            const int jb = je < hi ? je : hi;
+            const int ma = k - 1 - jb, mb = k - 1 - cur;
+            const double c1 = 2.0 * c.half_dt * c.sb[qq];
+            const double yc = c.sb[qq] * (t1 - c.st[qq]) + c.sy[qq];  // I0 at j = cur
+            acc += (yc + c1 * (double)mb) * (c.P0[mb + 1] - c.P0[ma]) - c1 * (c.Q0[mb + 1] - c.Q0[ma]) +
+                   c1 * (c.P1[mb + 1] - c.P1[ma]);
+            cur = jb + 1;
+        } else {
+            // a tap that straddles a simulation sample (or the snapped last one): from the definition
+            const double t0 = tau(2 * cur), t1 = tau(2 * cur + 1), t2 = tau(2 * cur + 2);
+            const double y0 = conv_interp_near(c, t0, qq), y1 = conv_interp_near(c, t1, qq),
+                         y2 = conv_interp_near(c, t2, qq);
+            const double *tt = c.T + 3 * (k - 1 - cur);
+            acc += (y1 * tt[0] + (y2 - y0) * tt[1] + (2 * (y2 - 2 * y1 + y0)) * tt[2]);
+            ++cur;
+        }
+    }
+    return acc;
+}
+
+// first interval q with jhi[q] >= j (binary search; for random-access callers of conv_fast2)
+__device__ inline int conv_run_of(const ConvCtx &c, int64_t j)
+{
+    int lo = 0, hi = c.nt - 2;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (c.jhi[mid] < j) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_desc *__restrict__ descs,
                                                             const double *__restrict__ sig,
                                                             const double *__restrict__ tsteps,
@@ -296,8 +390,8 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
                                                             double neg_frac_tol, double *__restrict__ ll, int64_t B)
 {
     extern __shared__ double smem[];
-    __shared__ double red_v[kLikeBlock];
-    __shared__ int64_t red_i[kLikeBlock];
+    __shared__ double red_v[kLikeWaves];
+    __shared__ int64_t red_i[kLikeWaves];
     __shared__ int s_cnt[2];
     const int64_t sidx = blockIdx.x;
     if (sidx >= B) return;
@@ -323,6 +417,7 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
         const int nk = set.nk[ds.irf];
         const double *Tg = tables + set.off[ds.irf];
         double *T = wk, *P0 = T + 3 * nk, *Q0 = P0 + (nk + 1), *P1 = Q0 + (nk + 1);
+        int *jlo = reinterpret_cast<int *>(P1 + (nk + 1)), *jhi = jlo + nt;
         for (int i = tid; i < 3 * nk; i += kLikeBlock) T[i] = Tg[i];
         __syncthreads();
         if (tid < 3) {  // prefix sums of the moment table (sequential: same rounding every time)
@@ -344,22 +439,25 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
         // len(np.arange(0, t_end + dt/4, dt/2)), laplace.py:68
         c.n_r = (int64_t)ceil((c.t_end + set.dt[ds.irf] / 4) / c.half_dt);
         c.nkk = (c.n_r - 1) / 2;  // last convolved index
+        if (c.n_r >= (int64_t)1 << 30) {  // index arithmetic below is 32-bit (a 2000 ns trace at 0.025 ns has n_r = 160 001)
+            for (int j = tid; j < nT; j += kLikeBlock) ll[sidx * nT + j] = __builtin_nan("");
+            return;
+        }
         const int64_t nkk = c.nkk, n_r = c.n_r;
         const double half_dt = c.half_dt, t_end = c.t_end;
+        c.jlo = jlo; c.jhi = jhi;
+        for (int q = tid; q < nt - 1; q += kLikeBlock) conv_runs(c, q, jlo[q], jhi[q]);
+        __syncthreads();
         // ---- pass A: argmax of the convolved trace (laplace.py:82) ----
         double best = 0.0;
         int64_t bi = nkk + 1;
         {
-            // contiguous run of outputs per thread: the interval guess carries over from k to k+1
-            const int64_t per = (nkk + kLikeBlock) / kLikeBlock;
-            const int64_t ka = (int64_t)tid * per, kb = (ka + per <= nkk + 1) ? ka + per : nkk + 1;
-            int qh = 0;
-            if (ka <= nkk) {
-                const int64_t lo0 = (ka - nk > 0) ? ka - nk : 0;
-                qh = conv_segment(c, resampled_time(2 * lo0 + 1, n_r, half_dt, t_end));
-            }
-            for (int64_t k = ka; k < kb; ++k) {
-                const double acc = conv_fast(c, k, qh);
+            // outputs interleaved over the threads: neighbouring lanes work on neighbouring k, so their
+            // windows share the runs (LDS broadcasts) and their prefix-sum indices are consecutive
+            // (conflict-free); the run pointer still only moves forward per thread
+            int qh = conv_run_of(c, (tid - nk > 0) ? tid - nk : 0);
+            for (int64_t k = tid; k <= nkk; k += kLikeBlock) {
+                const double acc = conv_fast2(c, k, qh);
                 if (argmax_better(acc, k, best, bi, nkk + 1)) { best = acc; bi = k; }
             }
         }
@@ -395,9 +493,8 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
                 if (idx > nkk) idx = nkk;
                 const double x0 = resampled_time(2 * (idx - 1), n_r, half_dt, t_end) - t_shift;
                 const double x1 = resampled_time(2 * idx, n_r, half_dt, t_end) - t_shift;
-                const int64_t lo0 = (idx - 1 - nk > 0) ? idx - 1 - nk : 0;
-                int qh = conv_segment(c, resampled_time(2 * lo0 + 1, n_r, half_dt, t_end));
-                const double h0 = conv_fast(c, idx - 1, qh), h1 = conv_fast(c, idx, qh);
+                int qh = conv_run_of(c, (idx - 1 - nk > 0) ? idx - 1 - nk : 0);
+                const double h0 = conv_fast2(c, idx - 1, qh), h1 = conv_fast2(c, idx, qh);
                 const double slope = (h1 - h0) / (x1 - x0);
                 v = slope * (te - x0) + h0;
             }
@@ -428,7 +525,9 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
         __syncthreads();
         if ((tid & 63) == 0) red_v[tid >> 6] = vmin;
         __syncthreads();
-        const double min_y = pow(10.0, fmin(fmin(red_v[0], red_v[1]), fmin(red_v[2], red_v[3])));
+        double vm = red_v[0];
+        for (int w = 1; w < kLikeWaves; ++w) vm = fmin(vm, red_v[w]);
+        const double min_y = pow(10.0, vm);
         if (tid == 0) {
             int lo = 0, hi = n_c;  // lower_bound of -min_y in -sol, exactly numpy's bisection
             while (lo < hi) {
@@ -473,7 +572,9 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
             if ((tid & 63) == 0) red_v[tid >> 6] = part;
             __syncthreads();
             if (tid == 0) {
-                double tot = -(red_v[0] + red_v[1] + red_v[2] + red_v[3]);
+                double tot = 0.0;
+                for (int w = 0; w < kLikeWaves; ++w) tot += red_v[w];
+                tot = -tot;
                 if (failed || tot != tot) tot = -__builtin_inf();
                 ll[sidx * nT + j] = tot;
             }
