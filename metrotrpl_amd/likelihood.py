@@ -21,7 +21,7 @@ from . import batch
 class LikelihoodEngine:
     def __init__(self, indexes, units, lengths, nx, meas_types, times, vals, uncs, sigma, iniPar, ini_mode="fluence",
                  model="std", hmax=4.0, rtol=None, atol=None, irf_tables=None, irf_convolution=None,
-                 scale_shift=None, force_min_y=False, device=0, ctx=None, fittables=None, sort_by_cost=True):
+                 scale_shift=None, force_min_y=False, device=0, ctx=None, fittables=None, sort_by_cost=True, parts=2):
         """times/vals/uncs: per-measurement 1-D arrays (as _times/_vals/_uncs of the
         reference's shared fields); sigma: {meas_type: model_uncertainty};
         irf_tables: {wavelength: (table [k,3], t_irf [k])} from make_I_tables;
@@ -69,6 +69,8 @@ class LikelihoodEngine:
                                                            L.dptr(dts)))
             self.irf_index = [waves.index(int(w)) if w else -1 for w in irf_convolution]
         self.sort_by_cost = bool(sort_by_cost)
+        self.parts = max(1, int(parts))
+        self._side = []
         self._cap = 0
 
     def _ensure(self, n_solves, nT):
@@ -119,14 +121,21 @@ class LikelihoodEngine:
         ld["force_min_y"] = int(self.force_min_y)
         ld["scale_shift"] = shift
         ld["sigma"] = np.tile(self.sigma, Cn)
-        if self.sort_by_cost and d.shape[0] > 1024:
-            # more solves than SIMDs: the hardware hands out workgroups in index order, so put the
-            # expensive ones first (longest-processing-time-first): the tightened-tolerance solves
-            # (tauP >> tauN, see DESIGN.md "error control") and the thin, fast-decaying films.
-            # Only the solve descriptors move; outputs keep their places (out_off), the likelihood
-            # descriptors and the ll table keep chain-major order.
+        # Over-subscribed launches (more solves than SIMDs) are cut into `parts` chain blocks that
+        # run on separate HIP streams: the likelihood kernel of one block overlaps the solve tail of
+        # the next.  Inside a block the expensive solves go first (the hardware hands out workgroups
+        # in index order): the tightened-tolerance ones, tauP >> tauN (DESIGN.md "error control").
+        # Only the solve descriptors move; outputs keep their places (out_off), the likelihood
+        # descriptors and the ll table stay chain-major.
+        n = d.shape[0]
+        parts = self.parts if (n > 2048 and self.nx <= 256) else 1
+        cuts = [(Cn * p // parts) * self.M for p in range(parts + 1)]
+        if self.sort_by_cost and n > 1024:
             tn, tp = st[:, self.indexes["tauN"]], st[:, self.indexes["tauP"]]
-            d = d[np.argsort(-(1.0 + tp / tn), kind="stable")]
+            key = -(1.0 + tp / tn)
+            order = np.concatenate([a + np.argsort(key[a:b], kind="stable") for a, b in zip(cuts[:-1], cuts[1:])])
+            d = d[order]
+        self._cuts = cuts
         return d, ini_arr, ld
 
     def upload(self, states):
@@ -138,18 +147,44 @@ class LikelihoodEngine:
         self.d_like = torch.from_numpy(ld.view(np.uint8).reshape(-1)).to(self.dev)
 
     def launch(self, d_T, nT, stream=None):
-        """Enqueue solve + likelihood for the uploaded states on `stream` (torch stream)."""
+        """Enqueue solve + likelihood for the uploaded states on `stream` (torch stream); with
+        several parts the extra streams fork from and join back into it."""
         torch = self.torch
         self._ensure(self.n_solves, nT)
-        s = (stream or torch.cuda.current_stream()).cuda_stream
+        main = stream or torch.cuda.current_stream()
         lib, h = L.lib(), self.ctx.handle
-        self.ctx.check(lib.mtrpl_solve_batch_dev(h, self.n_solves, self.d_descs.data_ptr(), self.d_ini.data_ptr(),
-                                                 self.d_t.data_ptr(), self.d_sig.data_ptr(), self.d_status.data_ptr(),
-                                                 self.d_stats.data_ptr(), self.nx, L.MODEL[self.model], s))
-        self.ctx.check(lib.mtrpl_loglik_batch_dev(h, self.n_solves, self.d_like.data_ptr(), self.d_sig.data_ptr(),
-                                                  self.d_t.data_ptr(), self.d_exp_t.data_ptr(), self.d_exp_y.data_ptr(),
-                                                  self.d_exp_u.data_ptr(), d_T.data_ptr(), nT, self.max_nt,
-                                                  self.d_ll.data_ptr(), s))
+        cuts = self._cuts
+        n_parts = len(cuts) - 1
+        while len(self._side) < n_parts - 1:
+            self._side.append(torch.cuda.Stream(device=self.dev))
+        fork = None
+        if n_parts > 1:
+            fork = torch.cuda.Event()
+            fork.record(main)
+        joins = []
+        sd, sl = L.SOLVE_DESC_DTYPE.itemsize, L.LIKE_DESC_DTYPE.itemsize
+        for p in range(n_parts):
+            a, b = cuts[p], cuts[p + 1]
+            if b <= a:
+                continue
+            st = main if p == 0 else self._side[p - 1]
+            if p > 0:
+                st.wait_event(fork)
+            s = st.cuda_stream
+            self.ctx.check(lib.mtrpl_solve_batch_dev(h, b - a, self.d_descs.data_ptr() + a * sd, self.d_ini.data_ptr(),
+                                                     self.d_t.data_ptr(), self.d_sig.data_ptr(),
+                                                     self.d_status.data_ptr() + 4 * a, self.d_stats.data_ptr() + 32 * a,
+                                                     self.nx, L.MODEL[self.model], s))
+            self.ctx.check(lib.mtrpl_loglik_batch_dev(h, b - a, self.d_like.data_ptr() + a * sl, self.d_sig.data_ptr(),
+                                                      self.d_t.data_ptr(), self.d_exp_t.data_ptr(),
+                                                      self.d_exp_y.data_ptr(), self.d_exp_u.data_ptr(), d_T.data_ptr(),
+                                                      nT, self.max_nt, self.d_ll.data_ptr() + 8 * a * nT, s))
+            if p > 0:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                joins.append(ev)
+        for ev in joins:
+            main.wait_event(ev)
         return self.d_ll
 
     def eval(self, states, temperatures=(1.0,)):

@@ -59,7 +59,8 @@ def run(a, rank, world, local, dev):
     eng = LikelihoodEngine(W.indexes(), W.units(), W.STAUB_LENGTHS, nx, ["TRPL"] * 6, [times] * 6, vals, uncs,
                            {"TRPL": 1.0}, np.array(W.STAUB_FLUENCES), ini_mode="fluence", irf_tables=irf_tables,
                            irf_convolution=[745] * 6, device=local, ctx=ctx,
-                           sort_by_cost=os.environ.get("MTRPL_NO_SORT") != "1")
+                           sort_by_cost=os.environ.get("MTRPL_NO_SORT") != "1",
+                           parts=int(os.environ.get("MTRPL_PARTS", "2")))
     ens0 = W.pt_ensemble(n_chains, nx)
     T = ens0["temperatures"]
     d_T = torch.from_numpy(np.ascontiguousarray(T)).to(dev)
