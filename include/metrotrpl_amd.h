@@ -90,6 +90,8 @@ const char *mtrpl_version(void);
  *   e_weight                          relative error weight of the field components (x rtol_int)
  *   newton_tol, rate_max_age, rate_first_safety   simplified-Newton convergence control
  *   fresh_jac                         1: Jacobian re-evaluated at every refactorisation
+ *   early_factor, early_frac          local tolerance x early_factor for steps that end before
+ *                                     early_frac * (first requested sample time)
  *   honor_hmax                        1: desc.hmax is the maximum step (the reference's max_step)
  *   max_steps                         a solve that needs more stops early (status 1, tail zero-filled)
  *   kernel_variant                    1: team kernel also for nx <= 128 (test hook)

@@ -20,7 +20,7 @@ using namespace mtrpl;
 struct mtrpl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    SolveTuning tune{0.1, 3e-9, 3e-10, 1e-4, 2000000, 0.03, 8, 4.0, 1.0, 1, 0.5, 16.0, 1};
+    SolveTuning tune{0.1, 3e-9, 3e-10, 1e-4, 2000000, 0.03, 8, 4.0, 1.0, 1, 0.5, 16.0, 1, 10.0, 0.5};
     std::string err;
     // IRF tables resident on the device (mtrpl_irf_tables_upload)
     double *d_irf_tab = nullptr;
@@ -256,7 +256,8 @@ void launch_blk32(hipStream_t s, int64_t B, const mtrpl_solve_desc *d_descs, con
     const mtrpl32::mtrpl::SolveTuning t32{(float)t.rtol_scale, (float)t.rtol_cap, (float)t.rtol_floor,
                                           (float)t.atol_rel, t.max_steps, (float)t.newton_tol, t.rate_max_age,
                                           (float)t.rate_first_safety, (float)t.e_weight, t.honor_hmax,
-                                          (float)t.trts_rtol_factor, (float)t.amp_ref, t.fresh_jac};
+                                          (float)t.trts_rtol_factor, (float)t.amp_ref, t.fresh_jac,
+                                          (float)t.early_factor, (float)t.early_frac};
     hipLaunchKernelGGL((mtrpl32::mtrpl::solve_kernel_blk<W, false, GBLK>), dim3((unsigned)B), dim3(64 * W), 0, s,
                        d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, B, t32, reinterpret_cast<float2 *>(gblk));
 }
@@ -318,6 +319,8 @@ int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value)
     else if (k == "trts_rtol_factor") ctx->tune.trts_rtol_factor = value;
     else if (k == "amp_ref") ctx->tune.amp_ref = value;
     else if (k == "fresh_jac") ctx->tune.fresh_jac = (int)value;
+    else if (k == "early_factor") ctx->tune.early_factor = value;
+    else if (k == "early_frac") ctx->tune.early_frac = value;
     else if (k == "kernel_variant") ctx->kernel_variant = (int)value;
     else if (k == "precision") {
         if (value != 32 && value != 64) return bad(ctx, MTRPL_ERR_BAD_ARG, "precision must be 32 or 64");
@@ -344,6 +347,8 @@ int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value)
     else if (k == "trts_rtol_factor") *value = ctx->tune.trts_rtol_factor;
     else if (k == "amp_ref") *value = ctx->tune.amp_ref;
     else if (k == "fresh_jac") *value = ctx->tune.fresh_jac;
+    else if (k == "early_factor") *value = ctx->tune.early_factor;
+    else if (k == "early_frac") *value = ctx->tune.early_frac;
     else if (k == "kernel_variant") *value = ctx->kernel_variant;
     else if (k == "precision") *value = ctx->precision;
     else return MTRPL_ERR_BAD_ARG;

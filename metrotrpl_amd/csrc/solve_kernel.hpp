@@ -41,6 +41,8 @@ struct SolveTuning {
     double trts_rtol_factor;  // internal rtol of TRTS solves = this x that of TRPL solves (not below rtol_floor)
     double amp_ref;           // > 0: internal rtol /= max(1, (1 + tauP/tauN) / amp_ref); 0: off
     int fresh_jac;            // 1: every refactorisation re-evaluates the Jacobian at the current predictor
+    double early_factor;      // > 1: local tolerance x this for steps ending before early_frac * (first sample time)
+    double early_frac;
 };
 
 // Norms only steer step-size, order and Newton decisions: the f32 hardware square root (1 ulp of
@@ -316,6 +318,8 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
     // accumulated, so it gets a looser relative weight than the densities (DESIGN.md "error control")
     const double rtol_E = rtol * tune.e_weight;
     auto rtol_of = [&](int v) { return (v >= 2 * R && v < 3 * R) ? rtol_E : rtol; };
+    const double early_until = (nt > 1) ? tune.early_frac * ts[1] : 0.0;
+    const double early_inv = 1.0 / fmax(tune.early_factor, 1.0);
     const double newton_tol = (tune.newton_tol > 0.0)
                                   ? tune.newton_tol
                                   : fmax(10.0 * 2.220446049250313e-16 / rtol, fmin(0.03, sqrt(rtol)));
@@ -402,12 +406,15 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
             MTRPL_STAMP(ph_err);
             double yp[V], psi[V];
             double ialpha = 1.0, ec = 1.0;
+            // before the first requested sample only the slow content of the solution matters (fast spatial
+            // modes are damped by then): optional looser local tolerance for steps that end before it
+            const double early_scale = (tune.early_factor > 1.0 && t + h <= early_until) ? early_inv : 1.0;
             MTRPL_ORDER_SWITCH(order, (ndf_predict<K, V>(D, yp, psi), ialpha = NdfC<K>::ialpha, ec = NdfC<K>::errc))
             const double c = h * ialpha;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 psi[v] *= ialpha;
-                isc[v] = ctl_rcp(atol + rtol_of(v) * fabs(yp[v]));
+                isc[v] = ctl_rcp(atol + rtol_of(v) * fabs(yp[v])) * early_scale;
             }
             // simplified Newton
             MTRPL_STAMP(ph_pred);

@@ -146,6 +146,8 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
     // accumulated, so it gets a looser relative weight than the densities (DESIGN.md "error control")
     const double rtol_E = rtol * tune.e_weight;
     auto rtol_of = [&](int v) { return (v >= 2 * R && v < 3 * R) ? rtol_E : rtol; };
+    const double early_until = (nt > 1) ? tune.early_frac * ts[1] : 0.0;
+    const double early_inv = 1.0 / fmax(tune.early_factor, 1.0);
     const double newton_tol = (tune.newton_tol > 0.0)
                                   ? tune.newton_tol
                                   : fmax(10.0 * 2.220446049250313e-16 / rtol, fmin(0.03, sqrt(rtol)));
@@ -225,12 +227,15 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk(const mtrpl_solve_des
             // predictor
             double yp[V], psi[V];
             double ialpha = 1.0, ec = 1.0;
+            // before the first requested sample only the slow content of the solution matters (fast spatial
+            // modes are damped by then): optional looser local tolerance for steps that end before it
+            const double early_scale = (tune.early_factor > 1.0 && t + h <= early_until) ? early_inv : 1.0;
             MTRPL_ORDER_SWITCH(order, (ndf_predict<K, V>(D, yp, psi), ialpha = NdfC<K>::ialpha, ec = NdfC<K>::errc))
             const double c = h * ialpha;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 psi[v] *= ialpha;
-                isc[v] = ctl_rcp(atol + rtol_of(v) * fabs(yp[v]));
+                isc[v] = ctl_rcp(atol + rtol_of(v) * fabs(yp[v])) * early_scale;
             }
             // simplified Newton
             bool converged = false;
