@@ -87,7 +87,7 @@ const char *mtrpl_version(void);
  *   trts_rtol_factor                  ... x this for TRTS solves ...
  *   amp_ref                           ... / max(1, (1 + tauP/tauN) / amp_ref)   (0 = off), never below rtol_floor
  *   atol_rel                          internal atol = rtol_int * atol_rel * max(N0, P0)
- *   e_weight                          relative error weight of the field components (x rtol_int)
+ *   e_weight                          relative error weight of the field components (x rtol_int), TRPL solves only
  *   newton_tol, rate_max_age, rate_first_safety   simplified-Newton convergence control
  *   fresh_jac                         1: Jacobian re-evaluated at every refactorisation
  *   early_factor, early_frac          local tolerance x early_factor for steps that end before

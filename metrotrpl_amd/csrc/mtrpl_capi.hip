@@ -20,7 +20,7 @@ using namespace mtrpl;
 struct mtrpl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    SolveTuning tune{0.1, 3e-9, 3e-10, 1e-4, 2000000, 0.03, 8, 4.0, 1.0, 1, 0.5, 16.0, 1, 10.0, 0.5};
+    SolveTuning tune{0.1, 3e-9, 3e-10, 1e-4, 2000000, 0.03, 8, 4.0, 3.0, 1, 0.5, 16.0, 1, 10.0, 0.5};
     std::string err;
     // IRF tables resident on the device (mtrpl_irf_tables_upload)
     double *d_irf_tab = nullptr;

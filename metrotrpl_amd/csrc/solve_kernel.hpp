@@ -316,7 +316,8 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
     const double atol = rtol * tune.atol_rel * dNmax;
     // the field is a fast slaved variable (dielectric relaxation): its local error is damped, not
     // accumulated, so it gets a looser relative weight than the densities (DESIGN.md "error control")
-    const double rtol_E = rtol * tune.e_weight;
+    // (TRPL only: the photoconductivity weighs dP directly, and its p99 census error doubles with a looser field)
+    const double rtol_E = rtol * ((meas == MTRPL_MEAS_TRPL) ? tune.e_weight : 1.0);
     auto rtol_of = [&](int v) { return (v >= 2 * R && v < 3 * R) ? rtol_E : rtol; };
     const double early_until = (nt > 1) ? tune.early_frac * ts[1] : 0.0;
     const double early_inv = 1.0 / fmax(tune.early_factor, 1.0);
