@@ -12,6 +12,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 384
 NCH = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 NP = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 MEAS = sys.argv[4] if len(sys.argv) > 4 else "TRPL"
+TAG = sys.argv[5] if len(sys.argv) > 5 else ""
 c = W.config2(N)
 e = W.pt_ensemble(NCH)
 ix, un = W.indexes(), W.units()
@@ -36,6 +37,6 @@ if __name__ == "__main__":
             if i % 16 == 0:
                 print(i, time.time() - t0, flush=True)
     out = np.array(out)
-    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_cache", "census_refs.npz" if MEAS == "TRPL" else f"census_refs_{MEAS.lower()}.npz")
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_cache", ("census_refs" if MEAS == "TRPL" else f"census_refs_{MEAS.lower()}") + TAG + ".npz")
     np.savez_compressed(dst, cfg2=out[:N], pt=out[N:], n=N, nch=NCH)
     print("done", time.time() - t0)
