@@ -458,22 +458,31 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_r2(const mtrpl_solve_desc 
                     // iteration the rate of the previous steps with these same factors
                     // is carried over (Brown, Byrne & Hindmarsh 1989, VODE "crate")
                     double rate = rate_prev;
+                    // a correction two orders below the Newton tolerance ends the iteration whatever the
+                    // rate: near equilibrium (deep tail of a thin film at low fluence) successive
+                    // corrections are rounding noise of equal size, their ratio ~1 reads as divergence and
+                    // the step was halved and refactorised up to 200 times per solve for nothing
+                    const bool negligible = dn < 1e-2 * newton_tol;
                     if (k > 0) {
                         rate = dn * ctl_rcp(dn_old);
-                        double rp = rate;  // rate^(4-k)
-                        for (int q = 1; q < 4 - k; ++q) rp *= rate;
-                        if (rate >= 1.0 || rp * dn > newton_tol * (1.0 - rate)) break;
-                        // first measurement with new factors: take it (x rate_first_safety) instead
-                        // of smoothing down from 1 over several two-iteration steps
-                        rate_prev = (rate_prev >= 1.0 && tune.rate_first_safety > 0.0)
-                                        ? fmin(fmax(tune.rate_first_safety * rate, 1e-4), 0.9)
-                                        : fmax(0.3 * rate_prev, rate);
-                        rate_age = 0;
+                        if (!negligible) {
+                            double rp = rate;  // rate^(4-k)
+                            for (int q = 1; q < 4 - k; ++q) rp *= rate;
+                            if (rate >= 1.0 || rp * dn > newton_tol * (1.0 - rate)) break;
+                        }
+                        if (rate < 1.0) {  // (a ratio of two noise-level corrections is not a measurement)
+                            // first measurement with new factors: take it (x rate_first_safety) instead
+                            // of smoothing down from 1 over several two-iteration steps
+                            rate_prev = (rate_prev >= 1.0 && tune.rate_first_safety > 0.0)
+                                            ? fmin(fmax(tune.rate_first_safety * rate, 1e-4), 0.9)
+                                            : fmax(0.3 * rate_prev, rate);
+                            rate_age = 0;
+                        }
                     }
 #pragma unroll
                     for (int v = 0; v < V; ++v) { yn[v] += dy[v]; d[v] += dy[v]; }
                     const bool rate_ok = (k > 0) || (rate_prev < 0.9 && rate_age < tune.rate_max_age);
-                    if (dn == 0.0 || (rate_ok && rate < 1.0 && rate * dn < newton_tol * (1.0 - rate))) { converged = true; break; }
+                    if (negligible || (rate_ok && rate < 1.0 && rate * dn < newton_tol * (1.0 - rate))) { converged = true; break; }
                     dn_old = dn;
                 }
                 if (converged && n_iter == 1) rate_age++;
