@@ -232,7 +232,11 @@ def engine_from_fields(shared_fields, unique_fields, device=0, ctx=None):
     si = sf["_sim_info"]
     if "solver" in sf and sf["solver"][0] not in ("solveivp", "odeint", "diagnostic"):
         raise NotImplementedError("No solver available")  # forward_solver.py:225 (the NN surrogate is out of scope)
-    return LikelihoodEngine(sf["_param_indexes"], sf["units"], si["lengths"], si["nx"], si["meas_types"],
+    # read_config_script_file leaves sim_info["nx"] at its un-selected length (bayes_io.py:531-536); the
+    # reference indexes it by measurement number (utils.py:35), i.e. uses the leading entries
+    nx = np.asarray(si["nx"]).reshape(-1)
+    nx = nx[:len(si["lengths"])] if nx.size > 1 else nx
+    return LikelihoodEngine(sf["_param_indexes"], sf["units"], si["lengths"], nx, si["meas_types"],
                             sf["_times"], sf["_vals"], sf["_uncs"], unique_fields["model_uncertainty"],
                             sf["_init_params"], ini_mode=sf["ini_mode"], model=sf["model"], hmax=sf["hmax"],
                             rtol=sf.get("rtol"), atol=sf.get("atol"), irf_tables=sf.get("_IRF_tables") or None,
