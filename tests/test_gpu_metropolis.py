@@ -102,3 +102,40 @@ def test_main_from_config_script_and_csv_files(tmp_path, monkeypatch):
     back = S.load_pickle(str(tmp_path / "out" / "CPU0-final.pik"))
     np.testing.assert_array_equal(back.H.states, ens.H.states)
     assert back.ensemble_fields["ini_mode"] == "fluence" and back.latest_iter == 6
+
+
+def test_main_with_selection_scale_factors_and_tempering(tmp_path, monkeypatch):
+    """The file-driven flow with the options that re-index things: select_obs_sets keeps measurements
+    0, 2, 4 (sim_info["nx"] stays at full length, as the reference leaves it), two fittable scale
+    factors tied by a constraint group, a 3-rung ladder with swaps every 2 iterations."""
+    from metrotrpl_amd import forward_solver, main, sim_utils as S, workloads as W
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    text = open(os.path.join(golden, "configs", "default_terse.txt")).read()
+    text = text.replace("Inputs/fluences.csv", str(tmp_path / "flu.csv")).replace(
+        "Inputs/meas.csv", str(tmp_path / "meas.csv")).replace("bay_outputs/run", str(tmp_path / "out")).replace(
+        "Num iters: 100", "Num iters: 8").replace("Time cutoffs: 0\t2000", "Time cutoffs: 0\t100").replace(
+        "Select measurement: None", "Select measurement: 0\t2\t4")
+    text += ("Scale factor: 0.02\t[0, 2, 4]\t(0, 2)\t[1.0, 1.0, 1.0, 1.0, 1.5, 1.0]\n"
+             "Parallel tempering: 1\t3\t9\nTempering frequency: 2\n")
+    assert "Select measurement: 0\t2\t4" in text
+    (tmp_path / "mcmc0.txt").write_text(text)
+    ini = np.array(W.STAUB_FLUENCES, dtype=float)
+    np.savetxt(tmp_path / "flu.csv", ini, delimiter=",")
+    times = np.linspace(0, 200, 101)
+    ix, un, s0 = W.indexes(), W.units(), W.initial_state()
+    rows = []
+    for m in range(6):
+        g = S.Grid(W.STAUB_LENGTHS[m], 128, times, 4.0)
+        sig = forward_solver.solve(np.array(ini[m]), g, s0.copy(), ix, units=un, ini_mode="fluence")
+        rows.append(np.stack([times, sig * (1.5 if m == 4 else 1.0), 0.05 * sig], axis=1))
+    np.savetxt(tmp_path / "meas.csv", np.concatenate(rows), delimiter=",")
+    monkeypatch.chdir(tmp_path)
+    ens = main.run("mcmc", 0, serial_fallback=True)
+    ef = ens.ensemble_fields
+    assert ef["_sim_info"]["num_meas"] == 3 and list(ef["_sim_info"]["lengths"]) == [311, 311, 311]
+    assert ef["names"][-2:] == ["_s0", "_s2"]            # measurement 1 of the selection rides on _s0 (constraint group)
+    assert ens.H.states.shape == (3, 15, 8) and len(ef["_times"]) == 3 and len(ef["_times"][0]) == 51
+    # data were simulated at the initial guess with measurement 4 scaled by 1.5 = the initial guess of _s2
+    assert -1e-5 < ens.H.loglikelihood[0, 0] <= 0
+    assert np.all(np.isfinite(ens.H.loglikelihood)) and ens.H.swap_attempts.sum() == 3 * 2
+    assert ens.H.accept.sum() > 0
