@@ -246,7 +246,7 @@ def main():
                        "mean_rhs_evals": float(stats[:, 1].mean()), "max_integrator_steps": int(stats[:, 0].max()),
                        **({"options": a.opt} if a.opt else {}), **({"streams": S} if S > 1 else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "solve_kernel_r2",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "solve_kernel_nq",
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_solve": A,
                          "measured_stream_copy": copy_gbs,
                          "note": "state-streaming model of SURVEY.md 8d; the solve state is register-resident by "

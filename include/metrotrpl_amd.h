@@ -94,7 +94,8 @@ const char *mtrpl_version(void);
  *                                     early_frac * (first requested sample time)
  *   honor_hmax                        1: desc.hmax is the maximum step (the reference's max_step)
  *   max_steps                         a solve that needs more stops early (status 1, tail zero-filled)
- *   kernel_variant                    1: team kernel also for nx <= 128 (test hook)
+ *   kernel_variant                    std model, nx <= 128: 0 wave kernel with the Nordsieck-form BDF (default),
+ *                                     3 wave kernel with the NDF difference form, 1 team kernel (test hooks)
  *   precision                         64 (product) | 32 (fp32 build of the team kernel: precision sweep only) */
 int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value);
 int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value);

@@ -13,6 +13,7 @@
 #include "../../include/metrotrpl_amd.h"
 #include "irf_kernels.hpp"
 #include "solve_kernel_blk.hpp"
+#include "solve_kernel_nq.hpp"
 #include "mtrpl_fp32_pass.hpp"
 
 using namespace mtrpl;
@@ -31,7 +32,7 @@ struct mtrpl_ctx {
     // global scratch for the elimination blocks of the 4-wave (nx <= 512) kernel
     double2 *d_gblk = nullptr;
     size_t gblk_bytes = 0;
-    int kernel_variant = 0;  // 0: tuned wave kernel for std nx<=128; 1: always the team kernel
+    int kernel_variant = 0;  // std, nx<=128: 0 wave kernel (Nordsieck BDF); 3 wave kernel (NDF differences); 1 team kernel
     int precision = 64;      // 64: fp64 (the product); 32: the fp32 build of the team kernel (precision sweep only)
 };
 
@@ -388,7 +389,10 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
         return MTRPL_OK;
     }
     if (max_nx <= 128) {
-        if (!traps && ctx->kernel_variant == 0)
+        if (!traps && ctx->kernel_variant == 0)  // default: the wave kernel with the Nordsieck-form BDF
+            hipLaunchKernelGGL(solve_kernel_nq, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
+                               d_status, d_stats, B, ctx->tune);
+        else if (!traps && ctx->kernel_variant == 3)  // the wave kernel with the NDF difference form (previous default)
             hipLaunchKernelGGL(solve_kernel_r2, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
                                d_status, d_stats, B, ctx->tune);
         else if (!traps)
@@ -476,7 +480,7 @@ int mtrpl_rhs_batch(mtrpl_ctx *ctx, int64_t B, int32_t nx, int32_t model, const 
 #define MTRPL_RHS_LAUNCH(W_, T_)                                                                                  \
     hipLaunchKernelGGL((rhs_batch_kernel_blk<W_, T_>), dim3((unsigned)B), dim3(64 * W_), 0, s, dp.as<double>(), \
                        ddx.as<double>(), dy_in.as<double>(), dy_out.as<double>(), nx, B)
-    if (nx <= 128 && !traps && ctx->kernel_variant == 0)
+    if (nx <= 128 && !traps && ctx->kernel_variant != 1)
         hipLaunchKernelGGL(rhs_batch_kernel_r2, dim3((unsigned)B), dim3(64), 0, s, dp.as<double>(), ddx.as<double>(),
                            dy_in.as<double>(), dy_out.as<double>(), nx, B);
     else if (nx <= 128) { if (traps) MTRPL_RHS_LAUNCH(1, true); else MTRPL_RHS_LAUNCH(1, false); }
