@@ -259,6 +259,7 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_nq(const mtrpl_solve_desc 
     int io = 1;
     const double t_end = (nt > 1) ? ts[nt - 1] : 0.0;
     double tq_next = (nt > 1) ? ts[1] : 1e300;
+    int since_rej = 1000;  // accepted steps since the last rejected one
     double acp[V];  // the correction of the previous step (order-increase estimate)
 #pragma unroll
     for (int v = 0; v < V; ++v) acp[v] = 0.0;
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_nq(const mtrpl_solve_desc 
             dsm = wnorm<V>(w, inv_S) * inv_t2;
             if (dsm > 1.0) {
                 n_rej++;
+                since_rej = 0;
                 const double fac = fmax(0.2, safety * inv_root(dsm, order + 1));
                 MTRPL_ORDER_SWITCH(order, (nq_retract<K, V>(z), nq_rescale<K, V>(z, fac)))
                 h *= fac;
@@ -362,6 +364,7 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_nq(const mtrpl_solve_desc 
         if (!accepted) break;
         n_steps++;
         n_equal++;
+        since_rej++;
         t += h;
         MTRPL_ORDER_SWITCH(order, (nq_correct<K, V>(z, acor)))
         // dense output (Taylor polynomial of the Nordsieck array), forward_solver.py:167
@@ -408,11 +411,15 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_nq(const mtrpl_solve_desc 
         const double fm = (order > 1) ? pow_neg_inv(ddn, e0) : 0.0;
         const double f0 = pow_neg_inv(dsm, e1);
         const double fp = (order < 5) ? pow_neg_inv(dup, e2) : 0.0;
+        // stode's biases: a change of order has to promise more than staying (1.2 / 1.3 / 1.4)
         int dorder = 0;
-        double fbest = f0;
-        if (fm > fbest) { fbest = fm; dorder = -1; }
-        if (fp > fbest) { fbest = fp; dorder = 1; }
-        double fac = fmin(10.0, safety * fbest);
+        double fbest = f0 * tune.nq_bias_same;
+        if (fm * tune.nq_bias_down > fbest) { fbest = fm * tune.nq_bias_down; dorder = -1; }
+        if (fp * tune.nq_bias_up > fbest) { fbest = fp * tune.nq_bias_up; dorder = 1; }
+        double fac = fmin(10.0, (tune.nq_bias_same < 1.0 ? 1.0 : safety) * fbest);
+        // a step that was rejected a moment ago says the estimates behind `fac` are optimistic here (stiff
+        // surface terms): grow cautiously for a while instead of hunting (reject / shrink / regrow / reject)
+        if (since_rej < tune.nq_rej_memory) fac = fmin(fac, tune.nq_rej_growth);
         if (h * fac > hmax) fac = hmax * ih;
         if (dorder == 0 && fac >= 0.9 && fac < 1.2) {
             n_equal = order - 2;  // keep h and the factors; test again three steps on
