@@ -226,3 +226,26 @@ def test_hard_cases_tauP_much_larger_than_tauN():
         worst = max(worst, err)
         assert err <= 1e-6, (k, str(z["meas"][k]), err)
     print(f"hard cases: worst {worst:.2e}, steps {stats[:, 0].min()}..{stats[:, 0].max()}")
+
+
+def test_ndf_form_wave_kernel_still_agrees():
+    """kernel_variant 3 = the previous default (NDF backward differences): kept as a second,
+    independently written integrator for cross-checks -- both forms land on the converged traces."""
+    from metrotrpl_amd import _lib as L, batch
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "hard_cases.npz"))
+    idx = {n: i for i, n in enumerate(str(z["names"]).split(","))}
+    ctx = L.default_context()
+    out = {}
+    try:
+        for variant in (0, 3):
+            ctx.set_option("kernel_variant", variant)
+            out[variant] = batch.solve_batch(z["states"], idx, z["units"], z["iniPar"], z["thickness"], 128, z["tSteps"],
+                                             meas=[str(m) for m in z["meas"]])
+    finally:
+        ctx.set_option("kernel_variant", 0)
+    for k in range(len(z["sig"])):
+        ref = z["sig"][k]
+        m = np.abs(ref) >= 1e-4 * abs(ref[0])
+        for variant in (0, 3):
+            assert np.max(np.abs(out[variant][k][m] - ref[m]) / np.abs(ref[m])) <= 1e-6, (variant, k)
+    assert not np.array_equal(out[0], out[3])  # two different integrators, not one kernel behind two switches
