@@ -14,6 +14,7 @@
 #include "irf_kernels.hpp"
 #include "solve_kernel_blk.hpp"
 #include "solve_kernel_nq.hpp"
+#include "solve_kernel_blk_nq.hpp"
 #include "mtrpl_fp32_pass.hpp"
 
 using namespace mtrpl;
@@ -242,10 +243,14 @@ __global__ __launch_bounds__(64 * W) void rhs_batch_kernel_blk(const double *par
 template <int W, bool TRAPS, bool GBLK>
 void launch_blk(hipStream_t s, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
                 const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats,
-                const SolveTuning &tune, double2 *gblk)
+                const SolveTuning &tune, double2 *gblk, bool ndf_form = false)
 {
-    hipLaunchKernelGGL((solve_kernel_blk<W, TRAPS, GBLK>), dim3((unsigned)B), dim3(64 * W), 0, s, d_descs, d_ini,
-                       d_tsteps, d_out, d_status, d_stats, B, tune, gblk);
+    if (ndf_form)
+        hipLaunchKernelGGL((solve_kernel_blk<W, TRAPS, GBLK>), dim3((unsigned)B), dim3(64 * W), 0, s, d_descs, d_ini,
+                           d_tsteps, d_out, d_status, d_stats, B, tune, gblk);
+    else
+        hipLaunchKernelGGL((solve_kernel_blk_nq<W, TRAPS, GBLK>), dim3((unsigned)B), dim3(64 * W), 0, s, d_descs, d_ini,
+                           d_tsteps, d_out, d_status, d_stats, B, tune, gblk);
 }
 
 // fp32 build of the team kernel (mtrpl_fp32_pass.hpp); std model only
@@ -407,14 +412,14 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
             hipLaunchKernelGGL(solve_kernel_r2, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
                                d_status, d_stats, B, ctx->tune);
         else if (!traps)
-            launch_blk<1, false, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr);
+            launch_blk<1, false, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr, ctx->kernel_variant == 3);
         else
-            launch_blk<1, true, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr);
+            launch_blk<1, true, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr, ctx->kernel_variant == 3);
     } else if (max_nx <= 256) {
         if (!traps)
-            launch_blk<2, false, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr);
+            launch_blk<2, false, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr, ctx->kernel_variant == 3);
         else
-            launch_blk<2, true, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr);
+            launch_blk<2, true, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr, ctx->kernel_variant == 3);
     } else {
         // 4 waves per solve: the 21 elimination blocks per thread (172 KB per solve) do not fit
         // in LDS next to the exchange buffers -> per-solve slab in HBM (L2/MALL-resident)
@@ -427,9 +432,9 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
             ctx->gblk_bytes = need;
         }
         if (!traps)
-            launch_blk<4, false, true>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, ctx->d_gblk);
+            launch_blk<4, false, true>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, ctx->d_gblk, ctx->kernel_variant == 3);
         else
-            launch_blk<4, true, true>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, ctx->d_gblk);
+            launch_blk<4, true, true>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, ctx->d_gblk, ctx->kernel_variant == 3);
     }
     HIP_TRY(ctx, hipGetLastError());
     return MTRPL_OK;
