@@ -264,7 +264,12 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_nq(const mtrpl_solve_desc 
 #pragma unroll
     for (int v = 0; v < V; ++v) acp[v] = 0.0;
 
+#ifdef MTRPL_STAMPS
+    unsigned long long tlast_ = __builtin_amdgcn_s_memtime(), ph_sel = 0, ph_pred = 0, ph_fac = 0, ph_newt = 0,
+                       ph_err = 0, ph_upd = 0, ph_dense = 0;
+#endif
     while (io < nt) {
+        MTRPL_STAMP(ph_sel);
         if (n_steps >= tune.max_steps) { st = MTRPL_SOLVE_STOPPED_EARLY; break; }
         bool accepted = false;
         double acor[V], yn[V], isc[V];  // isc: 1/(atol + rtol*|y_predicted|), the error weights of this step
@@ -272,6 +277,7 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_nq(const mtrpl_solve_desc 
         int attempts = 0;
         while (!accepted) {
             if (++attempts > 60 || !(h > 1e-13 * fmax(t, 1e-3))) { st = MTRPL_SOLVE_STOPPED_EARLY; break; }
+            MTRPL_STAMP(ph_err);
             // predictor: z <- A z; z[0] is the predicted state, z[1] the predicted h*y'
             double el0 = 1.0, inv_t2 = 1.0;
             MTRPL_ORDER_SWITCH(order, (nq_predict<K, V>(z), el0 = NqC<K>::el0, inv_t2 = NqC<K>::inv_t2))
@@ -279,13 +285,16 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_nq(const mtrpl_solve_desc 
             const double early_scale = (tune.early_factor > 1.0 && t + h <= early_until) ? early_inv : 1.0;
 #pragma unroll
             for (int v = 0; v < V; ++v) isc[v] = ctl_rcp(atol + rtol_of(v) * fabs(z[0][v])) * early_scale;
+            MTRPL_STAMP(ph_pred);
             // simplified Newton on acor:  (I - h l0 J) dx = h f(y) - z[1] - acor,  y = z[0] + l0 acor
             bool converged = false, fresh = false;
             int n_iter = 0;
             while (!converged) {
                 if (!have_fac) {
+                    MTRPL_STAMP(ph_newt);
                     // the analytic Jacobian is evaluated inside the factorisation: always at the predictor
                     build_factors(p, z[0], c, lane, L, F);
+                    MTRPL_STAMP(ph_fac);
                     have_fac = true;
                     fresh = true;
                     n_fac++;
@@ -344,6 +353,7 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_nq(const mtrpl_solve_desc 
                 have_fac = false;
                 continue;
             }
+            MTRPL_STAMP(ph_newt);
             // 0.9 * (2*4 + 1) / (2*4 + n_iter), n_iter = 1..4
             safety = (n_iter == 1) ? 0.9 : ((n_iter == 2) ? 0.81 : ((n_iter == 3) ? 8.1 / 11.0 : 0.675));
 #pragma unroll
@@ -362,11 +372,13 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_nq(const mtrpl_solve_desc 
             }
         }
         if (!accepted) break;
+        MTRPL_STAMP(ph_err);
         n_steps++;
         n_equal++;
         since_rej++;
         t += h;
         MTRPL_ORDER_SWITCH(order, (nq_correct<K, V>(z, acor)))
+        MTRPL_STAMP(ph_upd);
         // dense output (Taylor polynomial of the Nordsieck array), forward_solver.py:167
         const double ih = frcp(h);
         while (io < nt) {
@@ -379,6 +391,7 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_nq(const mtrpl_solve_desc 
             io++;
             tq_next = (io < nt) ? ts[io] : 1e300;
         }
+        MTRPL_STAMP(ph_dense);
         if (n_equal < order + 1) {
 #pragma unroll
             for (int v = 0; v < V; ++v) acp[v] = acor[v];
@@ -457,6 +470,11 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_nq(const mtrpl_solve_desc 
             s[0] = n_steps; s[1] = n_rhs; s[2] = n_fac; s[3] = n_jac;
             s[4] = n_rej; s[5] = n_nfail; s[6] = order;
             s[7] = (int32_t)((__builtin_amdgcn_s_memtime() - clk0_) >> 4);  // residency of this solve, 16-tick units of the constant-rate counter
+#ifdef MTRPL_STAMPS
+            s[1] = (int)(ph_sel >> 10); s[2] = (int)(ph_pred >> 10); s[3] = (int)(ph_fac >> 10);
+            s[4] = (int)(ph_newt >> 10); s[5] = (int)(ph_err >> 10); s[6] = (int)(ph_upd >> 10);
+            s[7] = (int)(ph_dense >> 10);
+#endif
         }
     }
 }
