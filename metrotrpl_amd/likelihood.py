@@ -130,13 +130,30 @@ class LikelihoodEngine:
         n = d.shape[0]
         parts = self.parts if (n > 2048 and self.nx <= 256) else 1
         cuts = [(Cn * p // parts) * self.M for p in range(parts + 1)]
+        self._order = None
         if self.sort_by_cost and n > 1024:
-            tn, tp = st[:, self.indexes["tauN"]], st[:, self.indexes["tauP"]]
-            key = -(1.0 + tp / tn)
-            order = np.concatenate([a + np.argsort(key[a:b], kind="stable") for a, b in zip(cuts[:-1], cuts[1:])])
+            cost = self._measured_cost(n)
+            if cost is None:  # first launch: the tightened-tolerance solves (tauP >> tauN) are the slow ones
+                tn, tp = st[:, self.indexes["tauN"]], st[:, self.indexes["tauP"]]
+                cost = 1.0 + tp / tn
+            order = np.concatenate([a + np.argsort(-cost[a:b], kind="stable") for a, b in zip(cuts[:-1], cuts[1:])])
             d = d[order]
+            self._order = order
         self._cuts = cuts
         return d, ini_arr, ld
+
+    def _measured_cost(self, n):
+        """Residency of every solve in the previous launch (stats[7]), in chain-major order: Metropolis
+        proposals are small moves, so the last iteration's cost is the best predictor of this one's."""
+        prev = getattr(self, "_prev_order", None)
+        if prev is None or prev.shape[0] != n or getattr(self, "d_stats", None) is None:
+            return None
+        ticks = self.d_stats[:8 * n].view(-1, 8)[:, 7].cpu().numpy().astype(np.float64)
+        if not np.any(ticks > 0):
+            return None
+        cost = np.empty(n)
+        cost[prev] = ticks
+        return cost
 
     def upload(self, states):
         torch = self.torch
@@ -185,6 +202,7 @@ class LikelihoodEngine:
                 joins.append(ev)
         for ev in joins:
             main.wait_event(ev)
+        self._prev_order = self._order  # which solve sat where, for the cost read-back of the next launch
         return self.d_ll
 
     def eval(self, states, temperatures=(1.0,)):
