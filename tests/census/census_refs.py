@@ -6,7 +6,7 @@ import time
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 import numpy as np
 from multiprocessing import Pool
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from metrotrpl_amd import workloads as W
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 384
 NCH = int(sys.argv[2]) if len(sys.argv) > 2 else 64
@@ -37,6 +37,6 @@ if __name__ == "__main__":
             if i % 16 == 0:
                 print(i, time.time() - t0, flush=True)
     out = np.array(out)
-    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_cache", ("census_refs" if MEAS == "TRPL" else f"census_refs_{MEAS.lower()}") + TAG + ".npz")
+    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools", "_cache", ("census_refs" if MEAS == "TRPL" else f"census_refs_{MEAS.lower()}") + TAG + ".npz")
     np.savez_compressed(dst, cfg2=out[:N], pt=out[N:], n=N, nch=NCH)
     print("done", time.time() - t0)

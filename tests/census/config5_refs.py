@@ -6,7 +6,7 @@ import time
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 import numpy as np
 from multiprocessing import Pool
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from metrotrpl_amd import workloads as W
 NS = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 NP = int(sys.argv[2]) if len(sys.argv) > 2 else 7
@@ -29,6 +29,6 @@ if __name__ == "__main__":
             out.append(r)
             if i % 8 == 0:
                 print(i, time.time() - t0, flush=True)
-    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_cache", "config5_refs.npz")
+    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tools", "_cache", "config5_refs.npz")
     np.savez_compressed(dst, refs=np.array(out), n_states=NS)
     print("done", time.time() - t0)

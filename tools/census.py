@@ -1,4 +1,4 @@
-"""Accuracy census on the GPU box against the cached converged references (tools/census_refs.py),
+"""Accuracy census on the GPU box against the cached converged references (tests/census/census_refs.py),
 sweeping integrator options given as key=value[,value...] arguments (dev tool).
     python tools/census.py e_weight=1,100 honor_hmax=1,0 rtol_cap=3e-9"""
 import itertools

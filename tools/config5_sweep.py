@@ -1,6 +1,6 @@
 """BASELINE.json configs[4] / SURVEY.md 8d config 5: fp64 vs fp32 tolerance sweep at nx=512 (thick +
 thin film, TRPL + TRTS).  For every (precision, internal rtol) the 64-solve batch is integrated on the
-GPU and compared with the converged oracle (tools/config5_refs.py), per decade of signal decay.
+GPU and compared with the converged oracle (tests/census/config5_refs.py), per decade of signal decay.
     python tools/config5_sweep.py [out.json]"""
 import json
 import os

@@ -277,23 +277,17 @@ def ndf(prob, t_out, rtol, atol, hmax=np.inf, h0=None, newton_tol_frac=None, max
 
 
 if __name__ == "__main__":
-    from oracle import oracle as O
     from metrotrpl_amd import workloads as W
+    g = np.load("/root/repo/tests/golden/solve.npz", allow_pickle=True)
+    cv = np.load("/root/repo/tests/golden/solve_converged.npz", allow_pickle=True)
     ix = W.indexes()
-    un = W.units()
-    t = W.default_times()
-    c2 = W.config2(16)
-    cases = [("cfg3_m%d" % m, W.initial_state(), W.STAUB_FLUENCES[m], W.STAUB_LENGTHS[m]) for m in (0, 5)]
-    cases += [("cfg2_%d" % k, c2["states"][k], c2["iniPar"][k], 2000.0) for k in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3)]
-    for name, st, ini, th in cases:
-        g = O.Grid(th, 128, t, 4.0)
-        ost = {}
-        ref = O.solve(ini, g, st, ix, units=un, ini_mode="fluence", RTOL=1e-10, ATOL=1e-14, stats=ost)
-        prob = Problem(st, un, ix, ini, th, 128)
-        for rtol, atol in ((1e-6, 1e-12), (1e-7, 1e-13), (1e-8, 1e-14)):
+    for nm in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["cfg2_0", "cfg3_m0"]):
+        st, un, ini = g[nm + "__tight__state"], g[nm + "__tight__units"], g[nm + "__tight__iniPar"]
+        geom, t, ref = g[nm + "__tight__geom"], g[nm + "__tight__tSteps"], cv[nm + "__conv"]
+        prob = Problem(st, un, ix, ini, geom[0], int(geom[1]))
+        for rtol in (1e-7, 1e-8, 3e-9):
             t0 = time.time()
-            sig, s = ndf(prob, t, rtol, atol * np.max(prob.y0[:256]) / 1e-6, hmax=4.0)
-            m = ref > 1e-10 * ref[0]
+            sig, s = ndf(prob, t, rtol, rtol * 1e-4 * np.max(prob.y0[:2 * prob.nx]), hmax=4.0)
+            m = ref > 1e-4 * ref.max()
             rel = np.abs(sig - ref) / np.abs(ref)
-            print(f"{name} rtol={rtol:g}: maxrel={rel[m].max():.2e} med={np.median(rel[m]):.2e} decades={np.log10(ref[0]/ref[m][-1]):.1f} "
-                  f"{s} ({time.time()-t0:.1f}s) lsoda_tight={ost['nsteps']}")
+            print(f"{nm} rtol={rtol:g}: max4dec={rel[m].max():.2e} {s} ({time.time() - t0:.1f}s)")
