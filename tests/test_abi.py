@@ -63,3 +63,22 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(root, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "mtrpl_oracle" not in txt, f
                 assert "/root/reference" not in txt, f
+
+
+def test_only_tests_smoke_and_cpu_baseline_touch_the_oracle():
+    """oracle/ is checker infrastructure: besides tests/, only __graft_entry__ (build + smoke) and
+    bench.py's cpu_baseline import it; tools/ works from cached or committed traces."""
+    for root, _, files in os.walk(os.path.join(REPO, "tools")):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+    bench = open(os.path.join(REPO, "bench.py")).read()
+    uses = [i for i, line in enumerate(bench.split("\n")) if "from oracle" in line]
+    # both imports sit inside cpu_baseline() / its worker
+    src = bench.split("\n")
+    for i in uses:
+        j = i
+        while not src[j].startswith("def "):
+            j -= 1
+        assert src[j].startswith("def cpu_baseline") or src[j].startswith("def _cpu_one"), src[j]
