@@ -90,6 +90,7 @@ const char *mtrpl_version(void);
  *   e_weight                          relative error weight of the field components (x rtol_int), TRPL solves only
  *   newton_tol, rate_max_age, rate_first_safety   simplified-Newton convergence control
  *   fresh_jac                         1: Jacobian re-evaluated at every refactorisation
+ *   nq_deadband_hi                    a proposed step factor in [0.9, this) keeps the step and the factors (1.2)
  *   nq_rej_memory, nq_rej_growth      wave kernel: step growth capped at nq_rej_growth for nq_rej_memory accepted
  *                                     steps after a rejected one; nq_bias_same/_down/_up: multipliers of the step factors
  *   early_factor, early_frac          local tolerance x early_factor for steps that end before

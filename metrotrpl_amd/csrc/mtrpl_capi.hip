@@ -22,7 +22,7 @@ using namespace mtrpl;
 struct mtrpl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    SolveTuning tune{0.1, 3e-9, 3e-10, 1e-4, 2000000, 0.03, 8, 4.0, 3.0, 1, 0.5, 16.0, 1, 80, 1.2, 1.0, 1.0, 1.0, 10.0, 0.5};
+    SolveTuning tune{0.1, 3e-9, 3e-10, 1e-4, 2000000, 0.03, 8, 4.0, 3.0, 1, 0.5, 16.0, 1, 1.2, 80, 1.2, 1.0, 1.0, 1.0, 10.0, 0.5};
     std::string err;
     // IRF tables resident on the device (mtrpl_irf_tables_upload)
     double *d_irf_tab = nullptr;
@@ -263,7 +263,7 @@ void launch_blk32(hipStream_t s, int64_t B, const mtrpl_solve_desc *d_descs, con
                                           (float)t.atol_rel, t.max_steps, (float)t.newton_tol, t.rate_max_age,
                                           (float)t.rate_first_safety, (float)t.e_weight, t.honor_hmax,
                                           (float)t.trts_rtol_factor, (float)t.amp_ref, t.fresh_jac,
-                                          t.nq_rej_memory, (float)t.nq_rej_growth, (float)t.nq_bias_same, (float)t.nq_bias_down, (float)t.nq_bias_up,
+                                          (float)t.nq_deadband_hi, t.nq_rej_memory, (float)t.nq_rej_growth, (float)t.nq_bias_same, (float)t.nq_bias_down, (float)t.nq_bias_up,
                                           (float)t.early_factor, (float)t.early_frac};
     hipLaunchKernelGGL((mtrpl32::mtrpl::solve_kernel_blk<W, false, GBLK>), dim3((unsigned)B), dim3(64 * W), 0, s,
                        d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, B, t32, reinterpret_cast<float2 *>(gblk));
@@ -326,6 +326,7 @@ int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value)
     else if (k == "trts_rtol_factor") ctx->tune.trts_rtol_factor = value;
     else if (k == "amp_ref") ctx->tune.amp_ref = value;
     else if (k == "fresh_jac") ctx->tune.fresh_jac = (int)value;
+    else if (k == "nq_deadband_hi") ctx->tune.nq_deadband_hi = value;
     else if (k == "nq_rej_memory") ctx->tune.nq_rej_memory = (int)value;
     else if (k == "nq_rej_growth") ctx->tune.nq_rej_growth = value;
     else if (k == "nq_bias_same") ctx->tune.nq_bias_same = value;
@@ -359,6 +360,7 @@ int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value)
     else if (k == "trts_rtol_factor") *value = ctx->tune.trts_rtol_factor;
     else if (k == "amp_ref") *value = ctx->tune.amp_ref;
     else if (k == "fresh_jac") *value = ctx->tune.fresh_jac;
+    else if (k == "nq_deadband_hi") *value = ctx->tune.nq_deadband_hi;
     else if (k == "nq_rej_memory") *value = ctx->tune.nq_rej_memory;
     else if (k == "nq_rej_growth") *value = ctx->tune.nq_rej_growth;
     else if (k == "nq_bias_same") *value = ctx->tune.nq_bias_same;

@@ -41,6 +41,7 @@ struct SolveTuning {
     double trts_rtol_factor;  // internal rtol of TRTS solves = this x that of TRPL solves (not below rtol_floor)
     double amp_ref;           // > 0: internal rtol /= max(1, (1 + tauP/tauN) / amp_ref); 0: off
     int fresh_jac;            // 1: every refactorisation re-evaluates the Jacobian at the current predictor
+    double nq_deadband_hi;  // Nordsieck kernels: a step factor in [0.9, this) keeps h and the factors
     int nq_rej_memory; double nq_rej_growth;  // Nordsieck kernel: growth cap for this many steps after a rejection
     double nq_bias_same, nq_bias_down, nq_bias_up;  // Nordsieck kernel: multipliers of the step factors (stode: 1/1.2, 1/1.3, 1/1.4)
     double early_factor;      // > 1: local tolerance x this for steps ending before early_frac * (first sample time)

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_blk_nq(const mtrpl_solve_
         // surface terms): grow cautiously for a while instead of hunting (reject / shrink / regrow / reject)
         if (since_rej < tune.nq_rej_memory) fac = fmin(fac, tune.nq_rej_growth);
         if (h * fac > hmax) fac = hmax * ih;
-        if (dorder == 0 && fac >= 0.9 && fac < 1.2) {
+        if (dorder == 0 && fac >= 0.9 && fac < tune.nq_deadband_hi) {
             n_equal = order - 2;  // keep h and the factors; test again three steps on
             continue;
         }
