@@ -249,3 +249,23 @@ def test_ndf_form_wave_kernel_still_agrees():
         for variant in (0, 3):
             assert np.max(np.abs(out[variant][k][m] - ref[m]) / np.abs(ref[m])) <= 1e-6, (variant, k)
     assert not np.array_equal(out[0], out[3])  # two different integrators, not one kernel behind two switches
+
+
+def test_census_subset_within_gate():
+    """160 committed census traces (config-2 draws and PT-ensemble solves, thin and thick films, TRPL and
+    TRTS; tests/golden/make_census_subset.py): every one within 1e-6 of the converged oracle over the
+    4-decade window -- the regression guard of the tolerance policy."""
+    from metrotrpl_amd import batch
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "census_subset.npz"))
+    idx = {n: i for i, n in enumerate(str(z["names"]).split(","))}
+    sig, status, stats = batch.solve_batch(z["states"], idx, z["units"], z["iniPar"], z["thickness"], 128, z["tSteps"],
+                                           meas=[str(m) for m in z["meas"]], return_stats=True)
+    assert np.all(status == 0)
+    errs = np.zeros(len(sig))
+    for k in range(len(sig)):
+        ref = z["sig"][k]
+        m = np.abs(ref) >= 1e-4 * abs(ref[0])
+        errs[k] = np.max(np.abs(sig[k][m] - ref[m]) / np.abs(ref[m]))
+    print(f"census subset: max {errs.max():.2e} p90 {np.percentile(errs, 90):.2e} median {np.median(errs):.2e}")
+    assert errs.max() <= 1e-6, (int(errs.argmax()), errs.max())
+    assert np.median(errs) <= 1e-7
