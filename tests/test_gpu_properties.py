@@ -97,3 +97,19 @@ def test_thousands_of_prior_draws_all_integrate():
         # no runaway step counts; Newton failures (step halved) stay rare: deep tails of thin films at low
         # fluence still see a few when corrections reach rounding noise
         assert stats[:, 0].max() < 5000 and stats[:, 5].mean() < 0.2 and stats[:, 5].max() < 60
+
+
+def test_results_are_bitwise_reproducible_and_batch_independent():
+    """No atomics on floating-point data, no data-dependent scheduling of the arithmetic: the same solve gives
+    the same bits run to run, alone or inside a batch, whatever its position."""
+    from metrotrpl_amd import batch, workloads as W
+    c = W.config2(96)
+    ix, un = W.indexes(), W.units()
+    a = batch.solve_batch(c["states"], ix, un, c["iniPar"], 2000.0, 128, c["tSteps"])
+    b = batch.solve_batch(c["states"], ix, un, c["iniPar"], 2000.0, 128, c["tSteps"])
+    np.testing.assert_array_equal(a, b)
+    perm = np.random.default_rng(0).permutation(96)
+    p = batch.solve_batch(c["states"][perm], ix, un, c["iniPar"][perm], 2000.0, 128, c["tSteps"])
+    np.testing.assert_array_equal(p, a[perm])
+    one = batch.solve_batch(c["states"][17:18], ix, un, c["iniPar"][17:18], 2000.0, 128, c["tSteps"])
+    np.testing.assert_array_equal(one[0], a[17])
