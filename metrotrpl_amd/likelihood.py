@@ -132,7 +132,7 @@ class LikelihoodEngine:
         cuts = [(Cn * p // parts) * self.M for p in range(parts + 1)]
         self._order = None
         if self.sort_by_cost and n > 1024:
-            cost = self._measured_cost(n)
+            cost = self._measured_cost(n, states)
             if cost is None:  # first launch: the tightened-tolerance solves (tauP >> tauN) are the slow ones
                 tn, tp = st[:, self.indexes["tauN"]], st[:, self.indexes["tauP"]]
                 cost = 1.0 + tp / tn
@@ -142,11 +142,20 @@ class LikelihoodEngine:
         self._cuts = cuts
         return d, ini_arr, ld
 
-    def _measured_cost(self, n):
+    def _measured_cost(self, n, states):
         """Residency of every solve in the previous launch (stats[7]), in chain-major order: Metropolis
-        proposals are small moves, so the last iteration's cost is the best predictor of this one's."""
+        proposals are small moves, so the last iteration's cost is the best predictor of this one's.
+        Not used when the states are not a small move away from the previous ones (dense sampling)."""
         prev = getattr(self, "_prev_order", None)
+        last = getattr(self, "_prev_states", None)
+        self._prev_states = np.array(states, dtype=np.float64, copy=True)
         if prev is None or prev.shape[0] != n or getattr(self, "d_stats", None) is None:
+            return None
+        if last is None or last.shape != self._prev_states.shape:
+            return None
+        with np.errstate(all="ignore"):
+            ratio = np.abs(np.log(np.abs(self._prev_states) / np.abs(last)))
+        if not np.all(np.nan_to_num(ratio, nan=0.0) < 2.0):
             return None
         ticks = self.d_stats[:8 * n].view(-1, 8)[:, 7].cpu().numpy().astype(np.float64)
         if not np.any(ticks > 0):
