@@ -30,9 +30,9 @@ def test_cpu_baseline_shape():
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    """profiles/r01_k_bench_config2.json is a real `python bench.py` line from the MI355X box."""
+    """profiles/r01_m_bench_config2.json is a real `python bench.py` line from the MI355X box."""
     import json
-    d = json.load(open(os.path.join(REPO, "profiles", "r01_k_bench_config2.json")))
+    d = json.load(open(os.path.join(REPO, "profiles", "r01_m_bench_config2.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
