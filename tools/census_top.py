@@ -6,7 +6,6 @@ sys.path.insert(0, ROOT)
 from metrotrpl_amd import workloads as W, batch, _lib as L
 ix, un = W.indexes(), W.units()
 ctx = L.default_context()
-ctx.set_option("trts_rtol_factor", 1.0)
 for MEAS in ("TRPL", "TRTS"):
     z = np.load(os.path.join(ROOT, "tools", "_cache", "census_refs.npz" if MEAS == "TRPL" else "census_refs_trts.npz"))
     N, NCH = int(z["n"]), int(z["nch"])
