@@ -100,3 +100,23 @@ def test_units_none_and_list_state():
     a = solve([1.92e12, 6e4, 1], g, list(s0 * un), ix, ini_mode="fluence")
     b = solve([1.92e12, 6e4, 1], g, s0, ix, units=un, ini_mode="fluence")
     np.testing.assert_array_equal(a, b)
+
+
+def test_odd_and_tiny_grids_against_the_oracle():
+    """nx that is odd, tiny or not a multiple of the lanes' two nodes (2, 3, 5, 33, 101, 127) and the
+    wave kernel's maximum (128): padded lanes must stay inert.  Oracle: SciPy LSODA at 1e-10/1e-14
+    (converged to ~1e-8 over the first decades)."""
+    from metrotrpl_amd import batch, workloads as W
+    from oracle import oracle as O
+    O.build()
+    ix, un, s0 = W.indexes(), W.units(), W.initial_state()
+    t = np.linspace(0, 100, 51)
+    for nx in (2, 3, 5, 33, 101, 127, 128):
+        for thick, meas in ((311.0, "TRPL"), (2000.0, "TRTS")):
+            ini = np.array([1.92e12, 6e4, 1.0])
+            sig = batch.solve_batch(s0[None, :], ix, un, ini[None, :], thick, nx, t, meas=meas)[0]
+            g = O.Grid(thick, nx, t, 4.0)
+            ref = O.solve(ini, g, s0.copy(), ix, meas=meas, units=un, ini_mode="fluence", RTOL=1e-10, ATOL=1e-14)
+            m = ref >= 1e-3 * ref[0]
+            err = np.max(np.abs(sig[m] - ref[m]) / ref[m])
+            assert err < 1e-6, (nx, thick, meas, err)
