@@ -41,6 +41,8 @@ extern "C" {
 #define MTRPL_SOLVE_OK 0
 #define MTRPL_SOLVE_STOPPED_EARLY 1 /* integrator gave up: later samples computed
                                        from a zeroed state, like forward_solver.py:168 */
+#define MTRPL_SOLVE_OK_TOL_CLAMPED 2 /* solved; the requested RTOL was below the fp64 noise floor of
+                                        this system (option rtol_min) and was raised to it */
 
 enum { MTRPL_MEAS_TRPL = 0, MTRPL_MEAS_TRTS = 1 };    /* forward_solver.py:186-203 */
 enum { MTRPL_MODEL_STD = 0, MTRPL_MODEL_TRAPS = 1 };  /* forward_solver.py:420-423 */

@@ -1,0 +1,253 @@
+// backend_wave.hpp -- one 64-lane wavefront integrates one forward simulation: lane l owns the two
+// grid nodes 2l, 2l+1 (N_i, P_i and the edge field E_i on the LEFT face of each), so nx <= 128.  The
+// whole solver state lives on the CU (Nordsieck history and Newton vectors in this wave's VGPRs/AGPRs,
+// Newton matrix factors in its LDS slab); HBM is touched for the per-solve descriptor, the output
+// sample times and the nt output samples only.  The throughput kernel of a full batch: one wave per
+// SIMD, 1024 resident solves.
+//
+// Linear algebra of I - c*J (block tridiagonal, 2x2 blocks in (dN_i, dP_i) after the per-edge
+// elimination of the field, model_physics.hpp): one in-lane cyclic-reduction level followed by 6
+// parallel-cyclic-reduction levels over the 64 lanes (nearest-neighbour exchange by DPP wave shifts,
+// longer strides by ds_bpermute; one wave per workgroup, so no barriers); all 17 elimination blocks per
+// lane are kept in this wave's 34 KB LDS slab as 16-byte rows, so each further Newton iteration is a
+// cheap re-solve.
+#pragma once
+#include "solve_core.hpp"
+
+namespace mtrpl {
+
+constexpr int kFactorLdsBytes = 17 * 2 * 64 * 16;  // 34816 B per wave
+
+struct WaveBackend {
+    using real = double;
+    static constexpr int R = 2, V = 6;
+    static constexpr bool TRAPS = false;
+
+    Par p;
+    int L, lane;
+    Emitter em;
+    // factors
+    double w[2][2];    // dJ/dbE weights per own edge
+    double eco[2][4];  // dE_i = bE_i*minv - eco.(dN_{i-1}, dN_i, dP_{i-1}, dP_i)
+    double mvv[2];
+    double cd;         // c/dx
+    M2 Bfin;
+    // The 17 elimination blocks (in-lane CR: Binv_e, BiA_e, BiC_e, cr_al, cr_ga; PCR: al[6], ga[6]) live
+    // in this wave's LDS slab: [17 blocks][2 halves][64 lanes] x 16 B, i.e. every access is a
+    // conflict-free ds_read/write_b128 (lane stride 16 B).
+    double2 *lds;
+    enum { BINV_E = 0, BIA_E, BIC_E, CR_AL, CR_GA, PAL0, PGA0 = PAL0 + 6, NBLK = PGA0 + 6 };
+
+    __device__ inline WaveBackend(int lane_, double2 *lds_) : lane(lane_), lds(lds_) {}
+    __device__ inline int node(int r) const { return lane * R + r; }
+    __device__ inline bool leader() const { return lane == 0; }
+
+    __device__ inline void put(int blk, const M2 &m) const
+    {
+        lds[(blk * 2 + 0) * 64 + lane] = double2{m.a, m.b};
+        lds[(blk * 2 + 1) * 64 + lane] = double2{m.c, m.d};
+    }
+    __device__ inline M2 get(int blk) const
+    {
+        // Opaque lane index: keeps the block loads inside the Newton loop (16-B rows re-read from LDS
+        // every iteration) instead of letting the compiler hoist 64+ VGPRs of loop-invariant blocks and
+        // push the history out to AGPRs (measured: AGPRs 256 -> 116, 12.8 -> 12.3 ms per 1024-solve batch).
+        int l_ = lane;
+        asm volatile("" : "+v"(l_));
+        const double2 u = lds[(blk * 2 + 0) * 64 + l_], v = lds[(blk * 2 + 1) * 64 + l_];
+        return M2{u.x, u.y, v.x, v.y};
+    }
+
+    // ---- whole-grid primitives: everything is inside one wave ----
+    __device__ inline void publish(const double (&)[V], const double (&)[V]) {}
+    template <int NS>
+    __device__ inline void reduce(double (&s)[NS], const double (&)[V], const double (&)[V])
+    {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[k] = uniform(wave_sum(s[k]));
+    }
+    __device__ inline double scan_excl(double run) const { return wave_scan_incl(run, lane) - run; }
+    __device__ inline double max_all(double v) const { return wave_max(v); }
+    __device__ inline void out_begin(double *o, double min_y, double scale) { em.begin(o, min_y, scale); }
+    __device__ inline void out_sample(int k, double partial) { em.put(k, uniform(wave_sum(partial)), p.dx, lane == 0); }
+    __device__ inline void out_finish() {}
+
+    // ---- RHS: forward_solver.py:332-372 (dydt_numba) ----
+    // Padded nodes (i >= L) carry N=P=1, E=0 and get f=0.
+    __device__ inline void rhs(const double (&y)[V], double (&f)[V]) const
+    {
+        double Jn[R + 1], Jp[R + 1];
+        const double Nl = from_prev(y[R - 1]);
+        const double Pl = from_prev(y[2 * R - 1]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = lane * R + r;
+            const double N = y[r], P = y[R + r], E = y[2 * R + r];
+            const double Nm = (r == 0) ? Nl : y[(r == 0) ? 0 : r - 1];
+            const double Pm = (r == 0) ? Pl : y[R + ((r == 0) ? 0 : r - 1)];
+            double jn, jp;
+            edge_flux(p, Nm, N, Pm, P, E, jn, jp);  // :356-359
+            if (i == 0) {  // :346-351
+                const double Sft = surface_term(p, p.Sf, N, P);
+                jn = Sft;
+                jp = -Sft;
+            }
+            if (i >= L) { jn = 0.0; jp = 0.0; }
+            Jn[r] = jn;
+            Jp[r] = jp;
+        }
+        Jn[R] = from_next(Jn[0]);
+        Jp[R] = from_next(Jp[0]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = lane * R + r;
+            const double N = y[r], P = y[R + r];
+            const double NP = N * P - p.n0p0;
+            double jnr = Jn[r + 1], jpr = Jp[r + 1];
+            if (i == L - 1) {  // :347,:350,:352
+                const double Sbt = p.Sb * NP * frcp(N + P);
+                jnr = -Sbt;
+                jpr = Sbt;
+            }
+            const double recomb = bulk_recomb(p, N, P, NP);  // :366
+            const bool real_ = i < L;
+            f[r] = real_ ? ((jnr - Jn[r]) * p.idx - recomb) : 0.0;       // :369
+            f[R + r] = real_ ? (-(jpr - Jp[r]) * p.idx - recomb) : 0.0;  // :370
+            f[2 * R + r] = (real_ && i > 0) ? (-(Jn[r] + Jp[r]) * p.Lam) : 0.0;  // :363 (edge 0: exactly 0)
+        }
+    }
+
+    // ---- factorisation of M = I - c*J(yJ) ----
+    __device__ inline void build(const double (&y)[V], double c, double)
+    {
+        M2 Lm[R], Rm[R], A[R], B[R], C[R];
+        const double cL = c * p.Lam;
+        const double dnx = p.DnT * p.idx, dpx = p.DpT * p.idx;
+        const double Nl = from_prev(y[R - 1]);
+        const double Pl = from_prev(y[2 * R - 1]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = lane * R + r;
+            const double N = y[r], P = y[R + r], E = y[2 * R + r];
+            const double Nm = (r == 0) ? Nl : y[(r == 0) ? 0 : r - 1];
+            const double Pm = (r == 0) ? Pl : y[R + ((r == 0) ? 0 : r - 1)];
+            EdgeJac<double> ej = edge_jac_interior(p, cL, dnx, dpx, Nm, N, Pm, P, E);
+            if (i == 0) ej = edge_jac_front(p, N, P);
+            if (i >= L) ej = edge_jac_none<double>();
+            Lm[r] = ej.lm;
+            Rm[r] = ej.rm;
+            w[r][0] = ej.w0; w[r][1] = ej.w1;
+            eco[r][0] = ej.e0; eco[r][1] = ej.e1; eco[r][2] = ej.e2; eco[r][3] = ej.e3;
+            mvv[r] = ej.mv;
+        }
+        cd = c * p.idx;
+        // lane 63 wraps to lane 0's edge 0: harmless, its last node is the back surface or padding
+        const M2 LmNext = mnext(Lm[0]);
+        const M2 RmNext = mnext(Rm[0]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = lane * R + r;
+            const double N = y[r], P = y[R + r];
+            M2 lmn = (r == R - 1) ? LmNext : Lm[(r == R - 1) ? r : r + 1];
+            M2 rmn = (r == R - 1) ? RmNext : Rm[(r == R - 1) ? r : r + 1];
+            if (i == L - 1) {  // back surface: J_L = (-SL, SL)
+                double sLn, sLp;
+                surface_jac(p, p.Sb, N, P, sLn, sLp);
+                lmn = M2{-sLn, -sLp, sLn, sLp};
+                rmn = mzero<double>();
+            }
+            double RN, RP;
+            bulk_jac(p, N, P, RN, RP);
+            node_row(c, cd, Lm[r], Rm[r], lmn, rmn, RN, RP, A[r], B[r], C[r]);
+            if (i >= L) {
+                A[r] = mzero<double>();
+                C[r] = mzero<double>();
+                B[r] = mident<double>();
+            }
+        }
+        // in-lane cyclic reduction: row e = 2*lane (r=0) eliminated, row k = 2*lane+1 (r=1) kept
+        const M2 Binv_e = minv(B[0]);
+        put(BINV_E, Binv_e);
+        put(BIA_E, mmul(Binv_e, A[0]));
+        put(BIC_E, mmul(Binv_e, C[0]));
+        const M2 Binv_up = mnext(Binv_e);
+        const M2 A_up = mnext(A[0]);
+        const M2 C_up = mnext(C[0]);
+        const M2 cr_al = mmul(A[1], Binv_e);
+        const M2 cr_ga = mmul(C[1], Binv_up);
+        put(CR_AL, cr_al);
+        put(CR_GA, cr_ga);
+        M2 Ak = mneg(mmul(cr_al, A[0]));
+        M2 Ck = mneg(mmul(cr_ga, C_up));
+        M2 Bk = msub(msub(B[1], mmul(cr_al, C[0])), mmul(cr_ga, A_up));
+        // parallel cyclic reduction over the 64 kept rows
+#pragma unroll
+        for (int lv = 0; lv < 6; ++lv) {
+            const int s = 1 << lv;
+            const int lm_ = (lane - s) & 63, lp_ = (lane + s) & 63;
+            const M2 Bi = minv(Bk);
+            const M2 Bim = mshf(Bi, lm_), Bip = mshf(Bi, lp_);
+            const M2 Akm = mshf(Ak, lm_), Akp = mshf(Ak, lp_);
+            const M2 Ckm = mshf(Ck, lm_), Ckp = mshf(Ck, lp_);
+            const M2 al = mmul(Ak, Bim), ga = mmul(Ck, Bip);
+            put(PAL0 + lv, al);
+            put(PGA0 + lv, ga);
+            Bk = msub(msub(Bk, mmul(al, Ckm)), mmul(ga, Akp));
+            Ak = mneg(mmul(al, Akm));
+            Ck = mneg(mmul(ga, Ckp));
+        }
+        Bfin = minv(Bk);
+    }
+
+    // x = M^{-1} b; b, x in lane layout [N0,N1,P0,P1,E0,E1]
+    __device__ inline void apply(const double (&b)[V], double (&x)[V]) const
+    {
+        // E-elimination right-hand side
+        V2 wb[3];
+        wb[0] = V2{w[0][0] * b[4], w[0][1] * b[4]};
+        wb[1] = V2{w[1][0] * b[5], w[1][1] * b[5]};
+        wb[2] = vnext(wb[0]);  // lane 63 gets 0: its last node is the back surface or padding
+        V2 r[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const V2 nxt = wb[q + 1];  // edge L and padded edges carry zero weights
+            r[q] = V2{b[q] + cd * (nxt.x - wb[q].x), b[2 + q] - cd * (nxt.y - wb[q].y)};
+        }
+        // cyclic reduction of the right-hand side
+        const V2 re_up = vnext(r[0]);
+        const V2 t1 = mvec(get(CR_AL), r[0]), t2 = mvec(get(CR_GA), re_up);
+        V2 rk{r[1].x - t1.x - t2.x, r[1].y - t1.y - t2.y};
+#pragma unroll
+        for (int lv = 0; lv < 6; ++lv) {
+            const int s = 1 << lv;
+            const V2 rm = vshf(rk, (lane - s) & 63);
+            const V2 rp = vshf(rk, (lane + s) & 63);
+            const V2 u1 = mvec(get(PAL0 + lv), rm), u2 = mvec(get(PGA0 + lv), rp);
+            rk = V2{rk.x - u1.x - u2.x, rk.y - u1.y - u2.y};
+        }
+        const V2 xk = mvec(Bfin, rk);
+        const V2 xk_prev = vprev(xk);
+        const V2 s0 = mvec(get(BINV_E), r[0]), s1 = mvec(get(BIA_E), xk_prev), s2 = mvec(get(BIC_E), xk);
+        const V2 xe{s0.x - s1.x - s2.x, s0.y - s1.y - s2.y};
+        x[0] = xe.x; x[1] = xk.x; x[2] = xe.y; x[3] = xk.y;
+        // back-substitute the eliminated field unknowns
+        x[4] = b[4] * mvv[0] - (eco[0][0] * xk_prev.x + eco[0][1] * xe.x + eco[0][2] * xk_prev.y + eco[0][3] * xe.y);
+        x[5] = b[5] * mvv[1] - (eco[1][0] * xe.x + eco[1][1] * xk.x + eco[1][2] * xe.y + eco[1][3] * xk.y);
+    }
+};
+
+__global__ __launch_bounds__(64, 1) void solve_kernel_wave(const mtrpl_solve_desc *__restrict__ descs,
+                                                            const double *__restrict__ ini,
+                                                            const double *__restrict__ tsteps,
+                                                            double *__restrict__ out, int32_t *__restrict__ status,
+                                                            int32_t *__restrict__ stats, int64_t B, SolveTuning tune)
+{
+    const int64_t sidx = blockIdx.x;
+    const unsigned long long clk0_ = __builtin_amdgcn_s_memtime();
+    if (sidx >= B) return;
+    __shared__ double2 fac_lds[kFactorLdsBytes / 16];
+    WaveBackend bk(threadIdx.x & 63, fac_lds);
+    integrate(bk, descs[sidx], ini, tsteps, out, status, stats, sidx, tune, clk0_);
+}
+
+}  // namespace mtrpl

@@ -1,7 +1,7 @@
 // irf_kernels.hpp -- instrument-response convolution (laplace.py) and the
 // likelihood tail (trial_move_evaluation.py:96-158) on the device.
 #pragma once
-#include "solver_device.hpp"
+#include "device_math.hpp"
 
 namespace mtrpl {
 

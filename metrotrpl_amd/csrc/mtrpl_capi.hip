@@ -12,29 +12,42 @@
 
 #include "../../include/metrotrpl_amd.h"
 #include "irf_kernels.hpp"
-#include "solve_kernel_blk.hpp"
-#include "solve_kernel_nq.hpp"
-#include "solve_kernel_blk_nq.hpp"
-#include "mtrpl_fp32_pass.hpp"
+#include "backend_wave.hpp"
+#include "backend_pair.hpp"
+#include "backend_team.hpp"
 
 using namespace mtrpl;
+
+namespace {
+// Elimination-block slab of one in-flight nx > 256 launch (4 waves per solve keep their blocks in HBM).
+// A slab belongs to exactly one launch at a time: it is handed out again only once the event recorded
+// behind that launch has completed, or to a later launch on the SAME stream (stream order serialises).
+struct Slab {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+};
+}  // namespace
 
 struct mtrpl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    SolveTuning tune{0.1, 3e-9, 3e-10, 1e-4, 2000000, 0.03, 8, 4.0, 3.0, 1, 0.5, 16.0, 1, 1.2, 80, 1.2, 1.0, 1.0, 1.0, 10.0, 0.5};
+    SolveTuning tune{0.1, 3e-9, 3e-10, 1e-11, 1e-4, 2000000, 0.03, 8, 4.0, 3.0, 1, 0.5, 16.0, 1.2, 80, 1.2, 1.0, 1.0, 1.0, 10.0, 0.5};
     std::string err;
     // IRF tables resident on the device (mtrpl_irf_tables_upload)
     double *d_irf_tab = nullptr;
     std::vector<int32_t> irf_nk;
     std::vector<int64_t> irf_off;
     std::vector<double> irf_dt;
-    IrfTableSet *d_irf_set = nullptr;
-    // global scratch for the elimination blocks of the 4-wave (nx <= 512) kernel
-    double2 *d_gblk = nullptr;
-    size_t gblk_bytes = 0;
-    int kernel_variant = 0;  // std, nx<=128: 0 wave kernel (Nordsieck BDF); 3 wave kernel (NDF differences); 1 team kernel
+    std::vector<Slab> slabs;
+    // grow-only device scratch of the blocking host-pointer entry points (no hipMalloc/hipFree per call)
+    static constexpr int kScratch = 8;
+    void *scratch[kScratch] = {};
+    size_t scratch_cap[kScratch] = {};
+    int kernel_variant = 0;  // see include/metrotrpl_amd.h
     int precision = 64;      // 64: fp64 (the product); 32: the fp32 build of the team kernel (precision sweep only)
+    int pair_max_batch = 512;  // kernel_variant 0: launches up to this many solves use the wave-pair kernel
 };
 
 #define HIP_TRY(ctx, expr)                                                                   \
@@ -48,11 +61,27 @@ struct mtrpl_ctx {
 
 namespace {
 
-// RAII device buffer for the host-pointer entry points
+// device scratch slot `slot` of the context, at least n bytes; contents undefined
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 8); }
+    mtrpl_ctx *ctx;
+    int slot;
+    DevBuf(mtrpl_ctx *c, int s) : ctx(c), slot(s) {}
+    hipError_t alloc(size_t n)
+    {
+        if (n < 8) n = 8;
+        if (ctx->scratch_cap[slot] < n) {
+            if (ctx->scratch[slot]) (void)hipFree(ctx->scratch[slot]);
+            ctx->scratch[slot] = nullptr;
+            ctx->scratch_cap[slot] = 0;
+            const size_t cap = n + n / 4;
+            hipError_t e = hipMalloc(&ctx->scratch[slot], cap);
+            if (e != hipSuccess) return e;
+            ctx->scratch_cap[slot] = cap;
+        }
+        p = ctx->scratch[slot];
+        return hipSuccess;
+    }
     template <class T> T *as() { return static_cast<T *>(p); }
 };
 
@@ -63,71 +92,138 @@ int bad(mtrpl_ctx *ctx, int code, const char *msg)
 }
 
 // ---- small kernels for the reference's helper functions ------------------------
-// forward_solver.py:332-372 through the solver's own wave-layout RHS (R=2: nx<=128)
-__global__ __launch_bounds__(64) void rhs_batch_kernel_r2(const double *par, const double *dxs, const double *y,
-                                                          double *dy, int nx, int64_t B)
+// reference layouts: std [N(L),P(L),E(L+1)], traps [N(L),Ntrap(L),P(L),E(L+1)]
+template <class BK>
+__device__ inline void load_state(const BK &bk, const double *ys, int L, double (&yl)[BK::V], double pad_np)
 {
-    const int64_t s = blockIdx.x;
-    if (s >= B) return;
-    const int lane = threadIdx.x, L = nx, S = 3 * nx + 1;
-    const Par p = make_par(par + 16 * s, dxs[s]);
-    const double *ys = y + s * S;
-    double *fs = dy + s * S;
-    double yl[6], fl[6];
+    constexpr int R = BK::R;
+    const int oP = (BK::TRAPS ? 2 : 1) * L, oE = (BK::TRAPS ? 3 : 2) * L;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int i = lane * 2 + r;
-        yl[r] = (i < L) ? ys[i] : 1.0;
-        yl[2 + r] = (i < L) ? ys[L + i] : 1.0;
-        yl[4 + r] = (i < L) ? ys[2 * L + i] : 0.0;
+    for (int r = 0; r < R; ++r) {
+        const int i = bk.node(r);
+        yl[r] = (i < L) ? ys[i] : pad_np;
+        yl[R + r] = (i < L) ? ys[oP + i] : pad_np;
+        yl[2 * R + r] = (i < L) ? ys[oE + i] : 0.0;
+        if (BK::TRAPS) yl[3 * R + r] = (i < L) ? ys[L + i] : 0.0;
     }
-    rhs_std<2>(p, yl, fl, lane, L);
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int i = lane * 2 + r;
-        if (i < L) {
-            fs[i] = fl[r];
-            fs[L + i] = fl[2 + r];
-            fs[2 * L + i] = fl[4 + r];
-        }
-    }
-    if (lane == 0) fs[3 * L] = 0.0;  // dE_L = -(Jn_L + Jp_L)*Lambda = 0 (forward_solver.py:350-352,:363)
 }
 
-__global__ __launch_bounds__(64) void newton_probe_kernel_r2(const double *par, const double *dxs, const double *cs,
-                                                             const double *y, const double *b, double *x, int nx,
-                                                             int64_t B)
+// forward_solver.py:332-418 through a backend's own RHS
+template <class BK, class... LdsArgs>
+__device__ inline void rhs_probe(BK &bk, const double *par, const double *dxs, const double *y, double *dy, int nx,
+                                 int64_t s)
+{
+    constexpr int R = BK::R, V = BK::V;
+    const int L = nx, S = (BK::TRAPS ? 4 : 3) * nx + 1;
+    const int oP = (BK::TRAPS ? 2 : 1) * L, oE = (BK::TRAPS ? 3 : 2) * L;
+    bk.p = make_par<double>(par + 16 * s, dxs[s]);
+    bk.L = L;
+    double yl[V], fl[V], zs[V];
+    load_state(bk, y + s * S, L, yl, 1.0);
+#pragma unroll
+    for (int v = 0; v < V; ++v) zs[v] = 0.0;
+    bk.publish(yl, zs);
+    bk.rhs(yl, fl);
+    double *fs = dy + s * S;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = bk.node(r);
+        if (i < L) {
+            fs[i] = fl[r];
+            fs[oP + i] = fl[R + r];
+            fs[oE + i] = fl[2 * R + r];
+            if (BK::TRAPS) fs[L + i] = fl[3 * R + r];
+        }
+    }
+    if (bk.leader()) fs[oE + L] = 0.0;  // dE_L = -(Jn_L + Jp_L)*Lambda = 0 (forward_solver.py:350-352,:363)
+}
+
+__global__ __launch_bounds__(64) void rhs_batch_kernel_wave(const double *par, const double *dxs, const double *y,
+                                                            double *dy, int nx, int64_t B)
 {
     const int64_t s = blockIdx.x;
     if (s >= B) return;
-    const int lane = threadIdx.x, L = nx, S = 3 * nx + 1;
-    const Par p = make_par(par + 16 * s, dxs[s]);
-    double yl[6], bl[6], xl[6];
+    WaveBackend bk(threadIdx.x, nullptr);
+    rhs_probe(bk, par, dxs, y, dy, nx, s);
+}
+template <int W>
+__global__ __launch_bounds__(64 * W) void rhs_batch_kernel_pair(const double *par, const double *dxs, const double *y,
+                                                                double *dy, int nx, int64_t B)
+{
+    using BK = PairBackend<W, 6>;
+    const int64_t s = blockIdx.x;
+    if (s >= B) return;
+    __shared__ double2 xs_lds[BK::kXchBytes / 16];
+    BK bk(threadIdx.x, nullptr, reinterpret_cast<double *>(xs_lds));
+    rhs_probe(bk, par, dxs, y, dy, nx, s);
+}
+template <int W, bool TRAPS>
+__global__ __launch_bounds__(64 * W) void rhs_batch_kernel_team(const double *par, const double *dxs, const double *y,
+                                                                double *dy, int nx, int64_t B)
+{
+    using BK = TeamBackend<double, W, TRAPS, true>;
+    const int64_t s = blockIdx.x;
+    if (s >= B) return;
+    __shared__ double2 xbuf_lds[BK::kXbufRows];
+    __shared__ double rbuf_lds[BK::kRbufVals];
+    BK bk(threadIdx.x, xbuf_lds, rbuf_lds, nullptr);
+    rhs_probe(bk, par, dxs, y, dy, nx, s);
+}
+
+// one Newton linear solve (I - c*J(y)) x = b through a backend's factorisation (std layout)
+template <class BK>
+__device__ inline void newton_probe(BK &bk, const double *par, const double *dxs, const double *cs, const double *y,
+                                    const double *b, double *x, int nx, int64_t s)
+{
+    constexpr int R = BK::R, V = BK::V;
+    const int L = nx, S = 3 * nx + 1;
+    bk.p = make_par<double>(par + 16 * s, dxs[s]);
+    bk.L = L;
+    double yl[V], bl[V], xl[V], zs[V];
+    load_state(bk, y + s * S, L, yl, 1.0);
+    load_state(bk, b + s * S, L, bl, 0.0);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int i = lane * 2 + r;
-        yl[r] = (i < L) ? y[s * S + i] : 1.0;
-        yl[2 + r] = (i < L) ? y[s * S + L + i] : 1.0;
-        yl[4 + r] = (i < L) ? y[s * S + 2 * L + i] : 0.0;
-        bl[r] = (i < L) ? b[s * S + i] : 0.0;
-        bl[2 + r] = (i < L) ? b[s * S + L + i] : 0.0;
-        bl[4 + r] = (i < L && i > 0) ? b[s * S + 2 * L + i] : 0.0;
+    for (int r = 0; r < R; ++r) {
+        if (bk.node(r) == 0) bl[2 * R + r] = 0.0;  // the E_0 row of I - cJ is an identity row
+        zs[r] = 0.0; zs[R + r] = 0.0;
+        zs[2 * R + r] = -bl[2 * R + r];  // with h = 0 the neighbouring group reads b_E of its boundary edge from here
     }
-    __shared__ double2 fac_lds[kFactorLdsBytes / 16];
-    Factors<2> F;
-    F.lds = fac_lds;
-    build_factors(p, yl, cs[s], lane, L, F);
-    apply_factors(F, bl, xl, lane, L);
+    bk.publish(yl, zs);
+    bk.build(yl, cs[s], 0.0);
+    bk.apply(bl, xl);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int i = lane * 2 + r;
+    for (int r = 0; r < R; ++r) {
+        const int i = bk.node(r);
         if (i < L) {
             x[s * S + i] = xl[r];
-            x[s * S + L + i] = xl[2 + r];
-            x[s * S + 2 * L + i] = (i > 0) ? xl[4 + r] : b[s * S + 2 * L];
+            x[s * S + L + i] = xl[R + r];
+            x[s * S + 2 * L + i] = (i > 0) ? xl[2 * R + r] : b[s * S + 2 * L];
         }
     }
-    if (lane == 0) x[s * S + 3 * L] = b[s * S + 3 * L];  // E_0 and E_L rows of I - cJ are identity rows
+    if (bk.leader()) x[s * S + 3 * L] = b[s * S + 3 * L];  // E_0 and E_L rows of I - cJ are identity rows
+}
+__global__ __launch_bounds__(64) void newton_probe_kernel_wave(const double *par, const double *dxs, const double *cs,
+                                                               const double *y, const double *b, double *x, int nx,
+                                                               int64_t B)
+{
+    const int64_t s = blockIdx.x;
+    if (s >= B) return;
+    __shared__ double2 fac_lds[kFactorLdsBytes / 16];
+    WaveBackend bk(threadIdx.x, fac_lds);
+    newton_probe(bk, par, dxs, cs, y, b, x, nx, s);
+}
+template <int W, int NREG>
+__global__ __launch_bounds__(64 * W) void newton_probe_kernel_pair(const double *par, const double *dxs,
+                                                                   const double *cs, const double *y, const double *b,
+                                                                   double *x, int nx, int64_t B)
+{
+    using BK = PairBackend<W, NREG>;
+    const int64_t s = blockIdx.x;
+    if (s >= B) return;
+    __shared__ double2 blk_lds[BK::kBlkBytes > 0 ? BK::kBlkBytes / 16 : 1];
+    __shared__ double2 xs_lds[BK::kXchBytes / 16];
+    BK bk(threadIdx.x, blk_lds, reinterpret_cast<double *>(xs_lds));
+    newton_probe(bk, par, dxs, cs, y, b, x, nx, s);
 }
 
 // forward_solver.py:26-38: one wave per row, any nx (chunked inclusive scan)
@@ -144,11 +240,7 @@ __global__ __launch_bounds__(64) void e_field_kernel(const double *N, const doub
     for (int base = 0; base < nx; base += 64) {
         const int j = base + lane;
         double v = (j < nx) ? ((pp[j] - p0) - (n[j] - n0)) : 0.0;
-#pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {
-            const double t = shf(v, (lane - s) & 63);
-            v += (lane >= s) ? t : 0.0;
-        }
+        v = wave_scan_incl(v, lane);
         v += carry;
         if (j < nx) e[j + 1] = corner_E + pref * v;
         carry = shf(v, 63);
@@ -198,82 +290,69 @@ int check_descs(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d, int64_t n_
     return MTRPL_OK;
 }
 
-// forward_solver.py:332-418 through the team RHS (any nx <= 128*W, std or traps);
-// reference layouts: std [N(L),P(L),E(L+1)], traps [N(L),Ntrap(L),P(L),E(L+1)]
-template <int W, bool TRAPS>
-__global__ __launch_bounds__(64 * W) void rhs_batch_kernel_blk(const double *par, const double *dxs, const double *y,
-                                                               double *dy, int nx, int64_t B)
+// a slab of at least `need` bytes that no in-flight launch on another stream is using
+int take_slab(mtrpl_ctx *ctx, size_t need, hipStream_t s, Slab **out)
 {
-    constexpr int V = TRAPS ? 8 : 6;
-    const int64_t s = blockIdx.x;
-    if (s >= B) return;
-    __shared__ double2 xbuf_lds[team_xbuf_bytes<W>() / 16];
-    __shared__ double rbuf_lds[5 * W + 4];
-    Team<W> tm;
-    tm.tid = threadIdx.x; tm.lane = threadIdx.x & 63; tm.wave = threadIdx.x >> 6;
-    tm.xbuf = xbuf_lds; tm.rbuf = rbuf_lds; tm.xpar = 0; tm.rpar = 0;
-    const int L = nx, S = (TRAPS ? 4 : 3) * nx + 1;
-    const int oP = (TRAPS ? 2 : 1) * L, oE = (TRAPS ? 3 : 2) * L;
-    const Par p = make_par(par + 16 * s, dxs[s]);
-    const double *ys = y + s * S;
-    double *fs = dy + s * S;
-    double yl[V], fl[V];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int i = tm.tid * 2 + r;
-        yl[r] = (i < L) ? ys[i] : 1.0;
-        yl[2 + r] = (i < L) ? ys[oP + i] : 1.0;
-        yl[4 + r] = (i < L) ? ys[oE + i] : 0.0;
-        if (TRAPS) yl[6 + r] = (i < L) ? ys[L + i] : 0.0;
+    Slab *pick = nullptr;
+    for (Slab &sl : ctx->slabs) {
+        const bool free_ = (sl.stream == s) || (hipEventQuery(sl.done) == hipSuccess);
+        if (free_ && sl.bytes >= need && (!pick || sl.bytes < pick->bytes)) pick = &sl;
     }
-    team_rhs<W, TRAPS>(tm, p, yl, fl, L);
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int i = tm.tid * 2 + r;
-        if (i < L) {
-            fs[i] = fl[r];
-            fs[oP + i] = fl[2 + r];
-            fs[oE + i] = fl[4 + r];
-            if (TRAPS) fs[L + i] = fl[6 + r];
+    if (!pick) {
+        Slab sl;
+        HIP_TRY(ctx, hipMalloc(&sl.p, need));
+        sl.bytes = need;
+        if (hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
+            (void)hipFree(sl.p);
+            return bad(ctx, MTRPL_ERR_DEVICE, "hipEventCreate failed");
         }
+        ctx->slabs.push_back(sl);
+        pick = &ctx->slabs.back();
     }
-    if (tm.tid == 0) fs[oE + L] = 0.0;  // dE_L = 0 (forward_solver.py:350-352,:363)
+    pick->stream = s;
+    *out = pick;
+    return MTRPL_OK;
 }
 
-template <int W, bool TRAPS, bool GBLK>
-void launch_blk(hipStream_t s, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
-                const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats,
-                const SolveTuning &tune, double2 *gblk, bool ndf_form = false)
+template <class T, int W, bool TRAPS, bool GBLK>
+void launch_team(hipStream_t s, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
+                 const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats,
+                 const SolveTuning &tune, void *gblk)
 {
-    if (ndf_form)
-        hipLaunchKernelGGL((solve_kernel_blk<W, TRAPS, GBLK>), dim3((unsigned)B), dim3(64 * W), 0, s, d_descs, d_ini,
-                           d_tsteps, d_out, d_status, d_stats, B, tune, gblk);
-    else
-        hipLaunchKernelGGL((solve_kernel_blk_nq<W, TRAPS, GBLK>), dim3((unsigned)B), dim3(64 * W), 0, s, d_descs, d_ini,
-                           d_tsteps, d_out, d_status, d_stats, B, tune, gblk);
+    hipLaunchKernelGGL((solve_kernel_team<T, W, TRAPS, GBLK>), dim3((unsigned)B), dim3(64 * W), 0, s, d_descs, d_ini,
+                       d_tsteps, d_out, d_status, d_stats, B, tune, gblk);
 }
-
-// fp32 build of the team kernel (mtrpl_fp32_pass.hpp); std model only
-template <int W, bool GBLK>
-void launch_blk32(hipStream_t s, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
-                  const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats,
-                  const SolveTuning &t, double2 *gblk)
+template <class T>
+int launch_team_any(mtrpl_ctx *ctx, hipStream_t s, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
+                    const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats, int32_t max_nx,
+                    bool traps)
 {
-    const mtrpl32::mtrpl::SolveTuning t32{(float)t.rtol_scale, (float)t.rtol_cap, (float)t.rtol_floor,
-                                          (float)t.atol_rel, t.max_steps, (float)t.newton_tol, t.rate_max_age,
-                                          (float)t.rate_first_safety, (float)t.e_weight, t.honor_hmax,
-                                          (float)t.trts_rtol_factor, (float)t.amp_ref, t.fresh_jac,
-                                          (float)t.nq_deadband_hi, t.nq_rej_memory, (float)t.nq_rej_growth, (float)t.nq_bias_same, (float)t.nq_bias_down, (float)t.nq_bias_up,
-                                          (float)t.early_factor, (float)t.early_frac};
-    hipLaunchKernelGGL((mtrpl32::mtrpl::solve_kernel_blk<W, false, GBLK>), dim3((unsigned)B), dim3(64 * W), 0, s,
-                       d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, B, t32, reinterpret_cast<float2 *>(gblk));
+#define MTRPL_TEAM(W_, G_, P_)                                                                                       \
+    do {                                                                                                             \
+        if (traps) launch_team<T, W_, true, G_>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, P_); \
+        else launch_team<T, W_, false, G_>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, P_);      \
+    } while (0)
+    if (max_nx <= 128) MTRPL_TEAM(1, false, nullptr);
+    else if (max_nx <= 256) MTRPL_TEAM(2, false, nullptr);
+    else {
+        // 4 waves per solve: the 21 elimination blocks per thread (172 KB per solve in fp64) do not fit in
+        // LDS next to the exchange buffers -> per-solve slab in HBM (L2/MALL-resident), private to this launch
+        const size_t need = (size_t)B * TeamBackend<T, 4, false, true>::kBlkRows * sizeof(typename TeamBackend<T, 4, false, true>::row_t);
+        Slab *sl = nullptr;
+        const int rc = take_slab(ctx, need, s, &sl);
+        if (rc != MTRPL_OK) return rc;
+        MTRPL_TEAM(4, true, sl->p);
+        HIP_TRY(ctx, hipEventRecord(sl->done, s));
+    }
+#undef MTRPL_TEAM
+    return MTRPL_OK;
 }
 
 }  // namespace
 
 extern "C" {
 
-const char *mtrpl_version(void) { return "metrotrpl_amd 0.1 (gfx950)"; }
+const char *mtrpl_version(void) { return "metrotrpl_amd 0.2 (gfx950)"; }
 
 int mtrpl_ctx_create(int device, mtrpl_ctx **out)
 {
@@ -299,9 +378,14 @@ int mtrpl_ctx_destroy(mtrpl_ctx *ctx)
 {
     if (!ctx) return MTRPL_OK;
     (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
     if (ctx->d_irf_tab) (void)hipFree(ctx->d_irf_tab);
-    if (ctx->d_irf_set) (void)hipFree(ctx->d_irf_set);
-    if (ctx->d_gblk) (void)hipFree(ctx->d_gblk);
+    for (Slab &sl : ctx->slabs) {
+        if (sl.p) (void)hipFree(sl.p);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    for (int k = 0; k < mtrpl_ctx::kScratch; ++k)
+        if (ctx->scratch[k]) (void)hipFree(ctx->scratch[k]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return MTRPL_OK;
@@ -309,66 +393,60 @@ int mtrpl_ctx_destroy(mtrpl_ctx *ctx)
 
 const char *mtrpl_last_error(const mtrpl_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 
+namespace {
+struct OptD { const char *key; double SolveTuning::*m; };
+struct OptI { const char *key; int SolveTuning::*m; };
+const OptD kOptD[] = {
+    {"rtol_scale", &SolveTuning::rtol_scale}, {"rtol_cap", &SolveTuning::rtol_cap},
+    {"rtol_floor", &SolveTuning::rtol_floor}, {"rtol_min", &SolveTuning::rtol_min},
+    {"atol_rel", &SolveTuning::atol_rel}, {"newton_tol", &SolveTuning::newton_tol},
+    {"rate_first_safety", &SolveTuning::rate_first_safety}, {"e_weight", &SolveTuning::e_weight},
+    {"trts_rtol_factor", &SolveTuning::trts_rtol_factor}, {"amp_ref", &SolveTuning::amp_ref},
+    {"nq_deadband_hi", &SolveTuning::nq_deadband_hi}, {"nq_rej_growth", &SolveTuning::nq_rej_growth},
+    {"nq_bias_same", &SolveTuning::nq_bias_same}, {"nq_bias_down", &SolveTuning::nq_bias_down},
+    {"nq_bias_up", &SolveTuning::nq_bias_up}, {"early_factor", &SolveTuning::early_factor},
+    {"early_frac", &SolveTuning::early_frac},
+};
+const OptI kOptI[] = {
+    {"max_steps", &SolveTuning::max_steps}, {"rate_max_age", &SolveTuning::rate_max_age},
+    {"honor_hmax", &SolveTuning::honor_hmax}, {"nq_rej_memory", &SolveTuning::nq_rej_memory},
+};
+}  // namespace
+
 int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value)
 {
     if (!ctx || !key) return MTRPL_ERR_BAD_ARG;
-    std::string k(key);
-    if (k == "rtol_scale") ctx->tune.rtol_scale = value;
-    else if (k == "rtol_cap") ctx->tune.rtol_cap = value;
-    else if (k == "rtol_floor") ctx->tune.rtol_floor = value;
-    else if (k == "atol_rel") ctx->tune.atol_rel = value;
-    else if (k == "max_steps") ctx->tune.max_steps = (int)value;
-    else if (k == "rate_max_age") ctx->tune.rate_max_age = (int)value;
-    else if (k == "newton_tol") ctx->tune.newton_tol = value;
-    else if (k == "rate_first_safety") ctx->tune.rate_first_safety = value;
-    else if (k == "e_weight") ctx->tune.e_weight = value;
-    else if (k == "honor_hmax") ctx->tune.honor_hmax = (int)value;
-    else if (k == "trts_rtol_factor") ctx->tune.trts_rtol_factor = value;
-    else if (k == "amp_ref") ctx->tune.amp_ref = value;
-    else if (k == "fresh_jac") ctx->tune.fresh_jac = (int)value;
-    else if (k == "nq_deadband_hi") ctx->tune.nq_deadband_hi = value;
-    else if (k == "nq_rej_memory") ctx->tune.nq_rej_memory = (int)value;
-    else if (k == "nq_rej_growth") ctx->tune.nq_rej_growth = value;
-    else if (k == "nq_bias_same") ctx->tune.nq_bias_same = value;
-    else if (k == "nq_bias_down") ctx->tune.nq_bias_down = value;
-    else if (k == "nq_bias_up") ctx->tune.nq_bias_up = value;
-    else if (k == "early_factor") ctx->tune.early_factor = value;
-    else if (k == "early_frac") ctx->tune.early_frac = value;
-    else if (k == "kernel_variant") ctx->kernel_variant = (int)value;
-    else if (k == "precision") {
+    const std::string k(key);
+    for (const OptD &o : kOptD)
+        if (k == o.key) { ctx->tune.*(o.m) = value; return MTRPL_OK; }
+    for (const OptI &o : kOptI)
+        if (k == o.key) { ctx->tune.*(o.m) = (int)value; return MTRPL_OK; }
+    if (k == "kernel_variant") {
+        const int v = (int)value;
+        if (v != 0 && v != 1 && v != 2 && v != 4 && v != 5)
+            return bad(ctx, MTRPL_ERR_BAD_ARG, "kernel_variant must be 0 (auto), 1 (team), 2 (wave), 4 or 5 (wave pair)");
+        ctx->kernel_variant = v;
+    } else if (k == "pair_max_batch") {
+        ctx->pair_max_batch = (int)value;
+    } else if (k == "precision") {
         if (value != 32 && value != 64) return bad(ctx, MTRPL_ERR_BAD_ARG, "precision must be 32 or 64");
         ctx->precision = (int)value;
+    } else {
+        return bad(ctx, MTRPL_ERR_BAD_ARG, "unknown option");
     }
-    else return bad(ctx, MTRPL_ERR_BAD_ARG, "unknown option");
     return MTRPL_OK;
 }
 
 int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value)
 {
     if (!ctx || !key || !value) return MTRPL_ERR_BAD_ARG;
-    std::string k(key);
-    if (k == "rtol_scale") *value = ctx->tune.rtol_scale;
-    else if (k == "rtol_cap") *value = ctx->tune.rtol_cap;
-    else if (k == "rtol_floor") *value = ctx->tune.rtol_floor;
-    else if (k == "atol_rel") *value = ctx->tune.atol_rel;
-    else if (k == "max_steps") *value = ctx->tune.max_steps;
-    else if (k == "rate_max_age") *value = ctx->tune.rate_max_age;
-    else if (k == "newton_tol") *value = ctx->tune.newton_tol;
-    else if (k == "rate_first_safety") *value = ctx->tune.rate_first_safety;
-    else if (k == "e_weight") *value = ctx->tune.e_weight;
-    else if (k == "honor_hmax") *value = ctx->tune.honor_hmax;
-    else if (k == "trts_rtol_factor") *value = ctx->tune.trts_rtol_factor;
-    else if (k == "amp_ref") *value = ctx->tune.amp_ref;
-    else if (k == "fresh_jac") *value = ctx->tune.fresh_jac;
-    else if (k == "nq_deadband_hi") *value = ctx->tune.nq_deadband_hi;
-    else if (k == "nq_rej_memory") *value = ctx->tune.nq_rej_memory;
-    else if (k == "nq_rej_growth") *value = ctx->tune.nq_rej_growth;
-    else if (k == "nq_bias_same") *value = ctx->tune.nq_bias_same;
-    else if (k == "nq_bias_down") *value = ctx->tune.nq_bias_down;
-    else if (k == "nq_bias_up") *value = ctx->tune.nq_bias_up;
-    else if (k == "early_factor") *value = ctx->tune.early_factor;
-    else if (k == "early_frac") *value = ctx->tune.early_frac;
-    else if (k == "kernel_variant") *value = ctx->kernel_variant;
+    const std::string k(key);
+    for (const OptD &o : kOptD)
+        if (k == o.key) { *value = ctx->tune.*(o.m); return MTRPL_OK; }
+    for (const OptI &o : kOptI)
+        if (k == o.key) { *value = ctx->tune.*(o.m); return MTRPL_OK; }
+    if (k == "kernel_variant") *value = ctx->kernel_variant;
+    else if (k == "pair_max_batch") *value = ctx->pair_max_batch;
     else if (k == "precision") *value = ctx->precision;
     else return MTRPL_ERR_BAD_ARG;
     return MTRPL_OK;
@@ -388,55 +466,31 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
     const bool traps = model == MTRPL_MODEL_TRAPS;
     if (ctx->precision == 32) {
         if (traps) return bad(ctx, MTRPL_ERR_UNSUPPORTED, "the fp32 build covers the std model only");
-        if (max_nx <= 128) {
-            launch_blk32<1, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr);
-        } else if (max_nx <= 256) {
-            launch_blk32<2, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr);
-        } else {
-            const size_t need = (size_t)B * team_blk_bytes<4>();
-            if (need > ctx->gblk_bytes) {
-                if (ctx->d_gblk) (void)hipFree(ctx->d_gblk);
-                ctx->d_gblk = nullptr;
-                ctx->gblk_bytes = 0;
-                HIP_TRY(ctx, hipMalloc((void **)&ctx->d_gblk, need));
-                ctx->gblk_bytes = need;
-            }
-            launch_blk32<4, true>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, ctx->d_gblk);
-        }
+        const int rc = launch_team_any<float>(ctx, s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, max_nx, false);
+        if (rc != MTRPL_OK) return rc;
         HIP_TRY(ctx, hipGetLastError());
         return MTRPL_OK;
     }
-    if (max_nx <= 128) {
-        if (!traps && ctx->kernel_variant == 0)  // default: the wave kernel with the Nordsieck-form BDF
-            hipLaunchKernelGGL(solve_kernel_nq, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
-                               d_status, d_stats, B, ctx->tune);
-        else if (!traps && ctx->kernel_variant == 3)  // the wave kernel with the NDF difference form (previous default)
-            hipLaunchKernelGGL(solve_kernel_r2, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
-                               d_status, d_stats, B, ctx->tune);
-        else if (!traps)
-            launch_blk<1, false, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr, ctx->kernel_variant == 3);
-        else
-            launch_blk<1, true, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr, ctx->kernel_variant == 3);
-    } else if (max_nx <= 256) {
-        if (!traps)
-            launch_blk<2, false, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr, ctx->kernel_variant == 3);
-        else
-            launch_blk<2, true, false>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, nullptr, ctx->kernel_variant == 3);
+    // std model, nx <= 128: the register-resident backends.
+    //   wave (2):  one wave per solve, two nodes per lane -- most solves per second in a full launch
+    //   pair (4):  two waves per solve, one node per lane, blocks in registers -- shortest solve when the
+    //              launch leaves SIMDs idle (B <= pair_max_batch: 2 B waves on 1024 SIMDs)
+    //   pair (5):  the same with every block in LDS and a register budget for two waves per SIMD
+    int variant = ctx->kernel_variant;
+    if (variant == 0) variant = (!traps && max_nx <= 128 && B <= ctx->pair_max_batch) ? 4 : 2;
+    if (traps || max_nx > 128 || variant == 1) {
+        const int rc = launch_team_any<double>(ctx, s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, max_nx, traps);
+        if (rc != MTRPL_OK) return rc;
+    } else if (variant == 4 || variant == 5) {
+#define MTRPL_PAIR(W_, NREG_, MINW_)                                                                                  \
+    hipLaunchKernelGGL((solve_kernel_pair<W_, NREG_, MINW_>), dim3((unsigned)B), dim3(64 * W_), 0, s, d_descs, d_ini, \
+                       d_tsteps, d_out, d_status, d_stats, B, ctx->tune)
+        if (max_nx <= 64) { if (variant == 4) MTRPL_PAIR(1, 6, 1); else MTRPL_PAIR(1, 0, 2); }
+        else { if (variant == 4) MTRPL_PAIR(2, 3, 1); else MTRPL_PAIR(2, 0, 2); }
+#undef MTRPL_PAIR
     } else {
-        // 4 waves per solve: the 21 elimination blocks per thread (172 KB per solve) do not fit
-        // in LDS next to the exchange buffers -> per-solve slab in HBM (L2/MALL-resident)
-        const size_t need = (size_t)B * team_blk_bytes<4>();
-        if (need > ctx->gblk_bytes) {
-            if (ctx->d_gblk) (void)hipFree(ctx->d_gblk);
-            ctx->d_gblk = nullptr;
-            ctx->gblk_bytes = 0;
-            HIP_TRY(ctx, hipMalloc((void **)&ctx->d_gblk, need));
-            ctx->gblk_bytes = need;
-        }
-        if (!traps)
-            launch_blk<4, false, true>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, ctx->d_gblk, ctx->kernel_variant == 3);
-        else
-            launch_blk<4, true, true>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, ctx->d_gblk, ctx->kernel_variant == 3);
+        hipLaunchKernelGGL(solve_kernel_wave, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
+                           d_status, d_stats, B, ctx->tune);
     }
     HIP_TRY(ctx, hipGetLastError());
     return MTRPL_OK;
@@ -451,7 +505,7 @@ int mtrpl_solve_batch(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *descs, 
     int rc = check_descs(ctx, B, descs, n_ini, tsteps, n_t, n_out);
     if (rc != MTRPL_OK) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf dd, di, dt, dout, dst, dstat;
+    DevBuf dd(ctx, 0), di(ctx, 1), dt(ctx, 2), dout(ctx, 3), dst(ctx, 4), dstat(ctx, 5);
     HIP_TRY(ctx, dd.alloc(sizeof(mtrpl_solve_desc) * B));
     HIP_TRY(ctx, di.alloc(sizeof(double) * (size_t)n_ini));
     HIP_TRY(ctx, dt.alloc(sizeof(double) * (size_t)n_t));
@@ -486,7 +540,7 @@ int mtrpl_rhs_batch(mtrpl_ctx *ctx, int64_t B, int32_t nx, int32_t model, const 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const bool traps = model == MTRPL_MODEL_TRAPS;
     const size_t S = (traps ? 4 : 3) * (size_t)nx + 1;
-    DevBuf dp, ddx, dy_in, dy_out;
+    DevBuf dp(ctx, 0), ddx(ctx, 1), dy_in(ctx, 2), dy_out(ctx, 3);
     HIP_TRY(ctx, dp.alloc(sizeof(double) * 16 * B));
     HIP_TRY(ctx, ddx.alloc(sizeof(double) * B));
     HIP_TRY(ctx, dy_in.alloc(sizeof(double) * S * B));
@@ -495,16 +549,21 @@ int mtrpl_rhs_batch(mtrpl_ctx *ctx, int64_t B, int32_t nx, int32_t model, const 
     HIP_TRY(ctx, hipMemcpyAsync(dp.p, par, sizeof(double) * 16 * B, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(ddx.p, dx, sizeof(double) * B, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(dy_in.p, y, sizeof(double) * S * B, hipMemcpyHostToDevice, s));
-#define MTRPL_RHS_LAUNCH(W_, T_)                                                                                  \
-    hipLaunchKernelGGL((rhs_batch_kernel_blk<W_, T_>), dim3((unsigned)B), dim3(64 * W_), 0, s, dp.as<double>(), \
-                       ddx.as<double>(), dy_in.as<double>(), dy_out.as<double>(), nx, B)
-    if (nx <= 128 && !traps && ctx->kernel_variant != 1)
-        hipLaunchKernelGGL(rhs_batch_kernel_r2, dim3((unsigned)B), dim3(64), 0, s, dp.as<double>(), ddx.as<double>(),
-                           dy_in.as<double>(), dy_out.as<double>(), nx, B);
-    else if (nx <= 128) { if (traps) MTRPL_RHS_LAUNCH(1, true); else MTRPL_RHS_LAUNCH(1, false); }
-    else if (nx <= 256) { if (traps) MTRPL_RHS_LAUNCH(2, true); else MTRPL_RHS_LAUNCH(2, false); }
-    else { if (traps) MTRPL_RHS_LAUNCH(4, true); else MTRPL_RHS_LAUNCH(4, false); }
-#undef MTRPL_RHS_LAUNCH
+#define MTRPL_RHS_ARGS dim3((unsigned)B), dim3(64 * W_), 0, s, dp.as<double>(), ddx.as<double>(), dy_in.as<double>(), dy_out.as<double>(), nx, B
+#define MTRPL_RHS_TEAM(W__, T_) do { constexpr int W_ = W__; hipLaunchKernelGGL((rhs_batch_kernel_team<W__, T_>), MTRPL_RHS_ARGS); } while (0)
+    const int variant = ctx->kernel_variant;
+    if (nx <= 128 && !traps && (variant == 4 || variant == 5)) {
+        if (nx <= 64) { constexpr int W_ = 1; hipLaunchKernelGGL((rhs_batch_kernel_pair<1>), MTRPL_RHS_ARGS); }
+        else { constexpr int W_ = 2; hipLaunchKernelGGL((rhs_batch_kernel_pair<2>), MTRPL_RHS_ARGS); }
+    } else if (nx <= 128 && !traps && variant != 1) {
+        constexpr int W_ = 1;
+        hipLaunchKernelGGL(rhs_batch_kernel_wave, MTRPL_RHS_ARGS);
+    }
+    else if (nx <= 128) { if (traps) MTRPL_RHS_TEAM(1, true); else MTRPL_RHS_TEAM(1, false); }
+    else if (nx <= 256) { if (traps) MTRPL_RHS_TEAM(2, true); else MTRPL_RHS_TEAM(2, false); }
+    else { if (traps) MTRPL_RHS_TEAM(4, true); else MTRPL_RHS_TEAM(4, false); }
+#undef MTRPL_RHS_TEAM
+#undef MTRPL_RHS_ARGS
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(dy, dy_out.p, sizeof(double) * S * B, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -520,7 +579,7 @@ int mtrpl_newton_probe(mtrpl_ctx *ctx, int64_t B, int32_t nx, const double *par,
     if (nx > 128) return bad(ctx, MTRPL_ERR_UNSUPPORTED, "nx > 128 not supported by this build");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t S = 3 * (size_t)nx + 1;
-    DevBuf dp, ddx, dc, dyy, db, dxo;
+    DevBuf dp(ctx, 0), ddx(ctx, 1), dc(ctx, 2), dyy(ctx, 3), db(ctx, 4), dxo(ctx, 5);
     HIP_TRY(ctx, dp.alloc(sizeof(double) * 16 * B));
     HIP_TRY(ctx, ddx.alloc(sizeof(double) * B));
     HIP_TRY(ctx, dc.alloc(sizeof(double) * B));
@@ -533,8 +592,17 @@ int mtrpl_newton_probe(mtrpl_ctx *ctx, int64_t B, int32_t nx, const double *par,
     HIP_TRY(ctx, hipMemcpyAsync(dc.p, c, sizeof(double) * B, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(dyy.p, y, sizeof(double) * S * B, hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(db.p, b, sizeof(double) * S * B, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(newton_probe_kernel_r2, dim3((unsigned)B), dim3(64), 0, s, dp.as<double>(), ddx.as<double>(),
-                       dc.as<double>(), dyy.as<double>(), db.as<double>(), dxo.as<double>(), nx, B);
+#define MTRPL_NP_ARGS 0, s, dp.as<double>(), ddx.as<double>(), dc.as<double>(), dyy.as<double>(), db.as<double>(), dxo.as<double>(), nx, B
+    const int variant = ctx->kernel_variant;
+    if (variant == 4 || variant == 5) {
+        if (nx <= 64 && variant == 4) hipLaunchKernelGGL((newton_probe_kernel_pair<1, 6>), dim3((unsigned)B), dim3(64), MTRPL_NP_ARGS);
+        else if (nx <= 64) hipLaunchKernelGGL((newton_probe_kernel_pair<1, 0>), dim3((unsigned)B), dim3(64), MTRPL_NP_ARGS);
+        else if (variant == 4) hipLaunchKernelGGL((newton_probe_kernel_pair<2, 3>), dim3((unsigned)B), dim3(128), MTRPL_NP_ARGS);
+        else hipLaunchKernelGGL((newton_probe_kernel_pair<2, 0>), dim3((unsigned)B), dim3(128), MTRPL_NP_ARGS);
+    } else {
+        hipLaunchKernelGGL(newton_probe_kernel_wave, dim3((unsigned)B), dim3(64), MTRPL_NP_ARGS);
+    }
+#undef MTRPL_NP_ARGS
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(x, dxo.p, sizeof(double) * S * B, hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -548,7 +616,7 @@ int mtrpl_E_field(mtrpl_ctx *ctx, int64_t rows, int32_t nx, const double *N, con
     if (rows <= 0) return MTRPL_OK;
     if (!N || !P || !E || nx < 1) return bad(ctx, MTRPL_ERR_BAD_ARG, "bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf dn, dpp, de;
+    DevBuf dn(ctx, 0), dpp(ctx, 1), de(ctx, 2);
     const size_t n = (size_t)rows * nx;
     HIP_TRY(ctx, dn.alloc(sizeof(double) * n));
     HIP_TRY(ctx, dpp.alloc(sizeof(double) * n));
@@ -572,7 +640,7 @@ static int integral_host(mtrpl_ctx *ctx, int64_t rows, int32_t nx, double dx, co
     if (rows <= 0) return MTRPL_OK;
     if (!N || !P || !out || nx < 1) return bad(ctx, MTRPL_ERR_BAD_ARG, "bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf dn, dpp, dout;
+    DevBuf dn(ctx, 0), dpp(ctx, 1), dout(ctx, 2);
     const size_t n = (size_t)rows * nx;
     HIP_TRY(ctx, dn.alloc(sizeof(double) * n));
     HIP_TRY(ctx, dpp.alloc(sizeof(double) * n));

@@ -55,8 +55,9 @@ def test_rhs_matches_reference(rhsg):
     """forward_solver.py:332-372 on random states (a4).  The kernel keeps the
     reference's operation order; hipcc may contract a*b+c, so agreement is to
     rounding of the individual flux terms, not bitwise."""
-    from metrotrpl_amd import batch
+    from metrotrpl_amd import _lib as L_, batch
     from metrotrpl_amd.forward_solver import q_C, eps0
+    ctx = L_.default_context()
     n = 0
     for k in range(int(rhsg["n_cases"])):
         a = rhsg[f"std{k}_args"]
@@ -66,19 +67,26 @@ def test_rhs_matches_reference(rhsg):
         par = np.array([[a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12],
                          q_C / (a[13] * eps0), a[14], 0, 0, 1]])
         y = rhsg[f"std{k}_y"]
-        dy = batch.rhs_batch(par, [a[1]], y[None, :], L)[0]
         ref = rhsg[f"std{k}_dy"]
         # dN, dP are differences of fluxes ~1e3x larger than the result: scale by the flux magnitude
         scale = np.max(np.abs(ref[:2 * L])) + 1e-300
-        np.testing.assert_allclose(dy[:2 * L], ref[:2 * L], rtol=1e-9, atol=1e-12 * scale)
-        np.testing.assert_allclose(dy[2 * L:], ref[2 * L:], rtol=1e-12, atol=1e-14 * np.max(np.abs(ref[2 * L:])))
+        for variant in (2, 4):  # the single-wave layout and the wave-pair layout (boundary node via LDS)
+            ctx.set_option("kernel_variant", variant)
+            try:
+                dy = batch.rhs_batch(par, [a[1]], y[None, :], L)[0]
+            finally:
+                ctx.set_option("kernel_variant", 0)
+            np.testing.assert_allclose(dy[:2 * L], ref[:2 * L], rtol=1e-9, atol=1e-12 * scale)
+            np.testing.assert_allclose(dy[2 * L:], ref[2 * L:], rtol=1e-12, atol=1e-14 * np.max(np.abs(ref[2 * L:])))
         n += 1
     assert n >= 4
 
 
 def test_newton_linear_solver():
-    """E-elimination + cyclic reduction == dense solve of (I - cJ) x = b."""
-    from metrotrpl_amd import batch, workloads as W
+    """E-elimination + cyclic reduction (+ the SPIKE interface of the wave-pair backend) == dense solve of
+    (I - cJ) x = b."""
+    from metrotrpl_amd import _lib as L, batch, workloads as W
+    ctx = L.default_context()
     from tools.proto_ndf import Problem
     ix, un = W.indexes(), W.units()
     c2 = W.config2(6)
@@ -97,10 +105,15 @@ def test_newton_linear_solver():
                 b[2 * nx] = 0.0
                 b[-1] = 0.0
                 x_ref = np.linalg.solve(M, b)
-                x = batch.newton_probe(par, [prob.dx], [c], y[None, :], b[None, :], nx)[0]
-                res = np.linalg.norm(M @ x - b) / np.linalg.norm(b)
-                assert res < 1e-6, (nx, k, c, res)
-                np.testing.assert_allclose(x, x_ref, rtol=1e-5, atol=1e-7 * np.max(np.abs(x_ref)))
+                for variant in (2, 4, 5):  # one wave | wave pair, blocks in registers | wave pair, blocks in LDS
+                    ctx.set_option("kernel_variant", variant)
+                    try:
+                        x = batch.newton_probe(par, [prob.dx], [c], y[None, :], b[None, :], nx)[0]
+                    finally:
+                        ctx.set_option("kernel_variant", 0)
+                    res = np.linalg.norm(M @ x - b) / np.linalg.norm(b)
+                    assert res < 1e-6, (variant, nx, k, c, res)
+                    np.testing.assert_allclose(x, x_ref, rtol=1e-5, atol=1e-7 * np.max(np.abs(x_ref)))
 
 
 def _run(c, rtol=None, atol=None):
@@ -228,27 +241,31 @@ def test_hard_cases_tauP_much_larger_than_tauN():
     print(f"hard cases: worst {worst:.2e}, steps {stats[:, 0].min()}..{stats[:, 0].max()}")
 
 
-def test_ndf_form_wave_kernel_still_agrees():
-    """kernel_variant 3 = the previous default (NDF backward differences): kept as a second,
-    independently written integrator for cross-checks -- both forms land on the converged traces."""
+def test_every_backend_lands_on_the_converged_traces():
+    """kernel_variant 2 (one wave per solve), 4 / 5 (wave pair: SPIKE interface between the waves, blocks in
+    registers / in LDS) and 1 (team kernel) are four different distributions of the same integrator: all
+    within the gate on the hard cases, and not one kernel behind four switches."""
     from metrotrpl_amd import _lib as L, batch
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "hard_cases.npz"))
     idx = {n: i for i, n in enumerate(str(z["names"]).split(","))}
     ctx = L.default_context()
     out = {}
+    variants = (2, 4, 5, 1)
     try:
-        for variant in (0, 3):
+        for variant in variants:
             ctx.set_option("kernel_variant", variant)
-            out[variant] = batch.solve_batch(z["states"], idx, z["units"], z["iniPar"], z["thickness"], 128, z["tSteps"],
-                                             meas=[str(m) for m in z["meas"]])
+            out[variant], status, stats = batch.solve_batch(z["states"], idx, z["units"], z["iniPar"], z["thickness"], 128,
+                                                            z["tSteps"], meas=[str(m) for m in z["meas"]], return_stats=True)
+            assert np.all(status == 0), variant
+            print(f"variant {variant}: steps {stats[:, 0].min()}..{stats[:, 0].max()}")
     finally:
         ctx.set_option("kernel_variant", 0)
     for k in range(len(z["sig"])):
         ref = z["sig"][k]
         m = np.abs(ref) >= 1e-4 * abs(ref[0])
-        for variant in (0, 3):
+        for variant in variants:
             assert np.max(np.abs(out[variant][k][m] - ref[m]) / np.abs(ref[m])) <= 1e-6, (variant, k)
-    assert not np.array_equal(out[0], out[3])  # two different integrators, not one kernel behind two switches
+    assert not np.array_equal(out[2], out[4]) and not np.array_equal(out[2], out[1])
 
 
 def test_census_subset_within_gate():
