@@ -74,6 +74,20 @@ struct PairBackend {
 #pragma unroll
         for (int k = 0; k < 4; ++k) pend[k] = 0.0;
     }
+    // One node per lane leaves VGPRs to spare while the scalar file is over-subscribed (the controller's
+    // state, the tuning constants, the pointers): the model parameters live in VGPRs here -- a VALU operand
+    // either way, and no v_readlane to fetch a spilled SGPR back.
+    static __device__ inline double in_vgpr(double x) { asm volatile("" : "+v"(x)); return x; }
+    __device__ inline void set_problem(const Par &q, int L_)
+    {
+        L = L_;
+        p.n0 = in_vgpr(q.n0); p.p0 = in_vgpr(q.p0); p.mun = in_vgpr(q.mun); p.mup = in_vgpr(q.mup);
+        p.ks = in_vgpr(q.ks); p.Cn = in_vgpr(q.Cn); p.Cp = in_vgpr(q.Cp); p.Sf = in_vgpr(q.Sf); p.Sb = in_vgpr(q.Sb);
+        p.tn = in_vgpr(q.tn); p.tp = in_vgpr(q.tp); p.Lam = in_vgpr(q.Lam); p.Tm = q.Tm;
+        p.kC = q.kC; p.Nt = q.Nt; p.tE = q.tE;
+        p.dx = in_vgpr(q.dx); p.idx = in_vgpr(q.idx); p.DnT = in_vgpr(q.DnT); p.DpT = in_vgpr(q.DpT);
+        p.n0p0 = in_vgpr(q.n0p0);
+    }
     __device__ inline int node(int) const { return nd; }
     __device__ inline bool leader() const { return nd == 0; }
 
@@ -123,7 +137,7 @@ struct PairBackend {
     {
         static_assert(NS <= 4, "record holds 4 sums + the boundary state");
 #pragma unroll
-        for (int k = 0; k < NS; ++k) s[k] = uniform(wave_sum(s[k]));
+        for (int k = 0; k < NS; ++k) s[k] = uniform(wave_sum_ctl(s[k]));
         if (W == 1) return;
         constexpr int KD = (NS + 4 + 1) & ~1;
         double mine[KD], th[KD];

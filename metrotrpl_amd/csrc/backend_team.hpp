@@ -52,6 +52,7 @@ struct TeamBackend {
         xpar = 0;
         rpar = 0;
     }
+    __device__ inline void set_problem(const ParT<real> &p_, int L_) { p = p_; L = L_; }
     __device__ inline int node(int r) const { return tid * R + r; }
     __device__ inline bool leader() const { return tid == 0; }
     __device__ inline void sync() const
@@ -98,7 +99,7 @@ struct TeamBackend {
     {
         static_assert(NS <= 4, "rbuf holds 4 sums per wave");
 #pragma unroll
-        for (int k = 0; k < NS; ++k) s[k] = wave_sum(s[k]);
+        for (int k = 0; k < NS; ++k) s[k] = wave_sum_ctl(s[k]);
         if (W == 1) return;
         real *r = rbuf + rpar * (4 * W);
         if (lane == 0) {
@@ -144,10 +145,18 @@ struct TeamBackend {
     __device__ inline void out_begin(double *o, double min_y, double scale) { em.begin(o, min_y, scale); }
     __device__ inline void out_sample(int k, real partial)
     {
-        real s1[1] = {partial};
-        const real dummy[V] = {};
-        reduce<1>(s1, dummy, dummy);
-        em.put(k, (double)s1[0], (double)p.dx, tid == 0);
+        // full-precision sum (reduce() is the controller-grade one)
+        real s = wave_sum(partial);
+        if (W > 1) {
+            real *r = rbuf + rpar * (4 * W);
+            if (lane == 0) r[wave] = s;
+            __syncthreads();
+            s = (real)0;
+#pragma unroll
+            for (int w_ = 0; w_ < W; ++w_) s += r[w_];
+            rpar ^= 1;
+        }
+        em.put(k, (double)s, (double)p.dx, tid == 0);
     }
     __device__ inline void out_finish() {}
 

@@ -39,6 +39,7 @@ struct WaveBackend {
     enum { BINV_E = 0, BIA_E, BIC_E, CR_AL, CR_GA, PAL0, PGA0 = PAL0 + 6, NBLK = PGA0 + 6 };
 
     __device__ inline WaveBackend(int lane_, double2 *lds_) : lane(lane_), lds(lds_) {}
+    __device__ inline void set_problem(const ParT<real> &p_, int L_) { p = p_; L = L_; }
     __device__ inline int node(int r) const { return lane * R + r; }
     __device__ inline bool leader() const { return lane == 0; }
 
@@ -64,7 +65,7 @@ struct WaveBackend {
     __device__ inline void reduce(double (&s)[NS], const double (&)[V], const double (&)[V])
     {
 #pragma unroll
-        for (int k = 0; k < NS; ++k) s[k] = uniform(wave_sum(s[k]));
+        for (int k = 0; k < NS; ++k) s[k] = uniform(wave_sum_ctl(s[k]));
     }
     __device__ inline double scan_excl(double run) const { return wave_scan_incl(run, lane) - run; }
     __device__ inline double max_all(double v) const { return wave_max(v); }

@@ -49,7 +49,7 @@ template <class T> __device__ inline T lane_value(T v, int src)
     return u.d;
 }
 
-// DPP move: lanes whose source is out of range or masked get 0.
+// DPP move with a partial row / bank mask: masked lanes (and lanes whose source is out of range) get 0.
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, class T>
 __device__ inline T dpp0(T v)
 {
@@ -60,25 +60,40 @@ __device__ inline T dpp0(T v)
         r.i[k] = __builtin_amdgcn_update_dpp(0, u.i[k], CTRL, ROW_MASK, BANK_MASK, false);
     return r.d;
 }
+// DPP move over all rows and banks with bound_ctrl: lanes whose source is out of range get 0 and no
+// lane keeps an old value, so the destination needs no initialisation (one v_mov_b32_dpp per dword).
+template <int CTRL, class T>
+__device__ inline T dppz(T v)
+{
+    union { T d; int i[sizeof(T) / 4]; } u, r;
+    u.d = v;
+#pragma unroll
+    for (unsigned k = 0; k < sizeof(T) / 4; ++k) r.i[k] = __builtin_amdgcn_mov_dpp(u.i[k], CTRL, 0xf, 0xf, true);
+    return r.d;
+}
 
 // Nearest-neighbour exchange across the whole wave as a DPP wave shift (2 VALU moves per double
 // instead of a ds_bpermute round trip).  The lane with no neighbour gets 0.
-template <class T> __device__ inline T from_prev(T v) { return dpp0<0x138>(v); }  // wave_shr:1: lane i <- lane i-1
-template <class T> __device__ inline T from_next(T v) { return dpp0<0x130>(v); }  // wave_shl:1: lane i <- lane i+1
+template <class T> __device__ inline T from_prev(T v) { return dppz<0x138>(v); }  // wave_shr:1: lane i <- lane i-1
+template <class T> __device__ inline T from_next(T v) { return dppz<0x130>(v); }  // wave_shl:1: lane i <- lane i+1
 
 // Sum over the 64 lanes, result wave-uniform (in SGPRs).  gfx9 DPP ladder: row_shr 1,2,4,8 inside
-// each row of 16, then row_bcast15 / row_bcast31 carry the row totals forward; the grand total
-// lands in lane 63.
+// each row of 16 (sources outside the row read as 0), then row_bcast15 / row_bcast31 carry the row
+// totals forward; the grand total lands in lane 63.
 template <class T> __device__ inline T wave_sum(T v)
 {
-    v += dpp0<0x111>(v);             // row_shr:1
-    v += dpp0<0x112>(v);             // row_shr:2
-    v += dpp0<0x114, 0xf, 0xe>(v);   // row_shr:4, banks 1-3
-    v += dpp0<0x118, 0xf, 0xc>(v);   // row_shr:8, banks 2-3
-    v += dpp0<0x142, 0xa>(v);        // row_bcast:15 -> rows 1,3
-    v += dpp0<0x143, 0xc>(v);        // row_bcast:31 -> rows 2,3
+    v += dppz<0x111>(v);        // row_shr:1
+    v += dppz<0x112>(v);        // row_shr:2
+    v += dppz<0x114>(v);        // row_shr:4
+    v += dppz<0x118>(v);        // row_shr:8
+    v += dpp0<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
+    v += dpp0<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
     return lane_value(v, 63);
 }
+// The same in f32 for quantities that only steer the controller (error norms): the DPP move folds into
+// the add (v_add_f32_dpp), a third of the instructions of the f64 ladder.
+__device__ inline double wave_sum_ctl(double v) { return (double)wave_sum((float)v); }
+__device__ inline float wave_sum_ctl(float v) { return wave_sum(v); }
 template <class T> __device__ inline T wave_max(T v)
 {
 #pragma unroll

@@ -216,7 +216,8 @@ __global__ void conv_time_kernel(int64_t n_conv, int64_t n_r, double half_dt, do
 // sample (and the snapped last one) are evaluated directly from the definition.
 constexpr int kLikeBlock = 768;   // 8 waves per trace: two blocks per CU keep 4 waves per SIMD in flight
 constexpr int kLikeWaves = kLikeBlock / 64;
-constexpr int kLikeMaxNt = 1024; // LDS budget (5 arrays of doubles + the run table)
+constexpr int kLikeLdsBytes = 160 * 1024;  // per-CU LDS: above this the per-sample arrays move to global memory
+constexpr int kLikeGworkBlocks = 1024;     // blocks of the global-work-space variant (4 per CU)
 
 struct ConvCtx {
     const double *st, *sy, *sb;   // LDS: times, values, slopes of the simulation intervals
@@ -379,34 +380,28 @@ __device__ inline int conv_run_of(const ConvCtx &c, int64_t j)
     return lo;
 }
 
-__global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_desc *__restrict__ descs,
-                                                            const double *__restrict__ sig,
-                                                            const double *__restrict__ tsteps,
-                                                            const double *__restrict__ exp_t,
-                                                            const double *__restrict__ exp_y,
-                                                            const double *__restrict__ exp_u,
-                                                            const double *__restrict__ temps, int nT, int max_nt,
-                                                            const double *__restrict__ tables, IrfTableSet set,
-                                                            double neg_frac_tol, double *__restrict__ ll, int64_t B)
+// One trace: everything the block needs sits behind the pointers it is given.  `work` holds the
+// per-sample arrays (6*max_nt doubles: times, signal, slopes, compared signal, 2u^2, run table), `irfw` the
+// IRF work space (moment table + its prefix sums); the kernel below decides which of them are LDS.
+__device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, const double *__restrict__ sig,
+                                    const double *__restrict__ tsteps, const double *__restrict__ exp_t,
+                                    const double *__restrict__ exp_y, const double *__restrict__ exp_u,
+                                    const double *__restrict__ temps, int nT, int max_nt,
+                                    const double *__restrict__ tables, const IrfTableSet &set, double neg_frac_tol,
+                                    double *__restrict__ ll, double *work, double *irfw, double *red_v,
+                                    int64_t *red_i, int *s_cnt)
 {
-    extern __shared__ double smem[];
-    __shared__ double red_v[kLikeWaves];
-    __shared__ int64_t red_i[kLikeWaves];
-    __shared__ int s_cnt[2];
-    const int64_t sidx = blockIdx.x;
-    if (sidx >= B) return;
-    const mtrpl_like_desc ds = descs[sidx];
     const int nt = ds.nt, n_exp = ds.n_exp, tid = threadIdx.x;
     if (nt > max_nt || n_exp > max_nt || n_exp > nt || nt < 2 || n_exp < 1) {  // caller broke its promise
         for (int j = tid; j < nT; j += kLikeBlock) ll[sidx * nT + j] = __builtin_nan("");
         return;
     }
-    double *st = smem;            // [nt] simulation times
+    double *st = work;            // [nt] simulation times
     double *sy = st + nt;         // [nt] simulated signal
     double *sb = sy + nt;         // [nt] interval slopes (laplace.py:74 via interp1d)
     double *sol = sb + nt;        // [n_exp] signal at the experimental times; later err^2
     double *su2 = sol + n_exp;    // [n_exp] 2*unc^2
-    double *wk = su2 + n_exp;     // IRF work space: T[3nk], P0,Q0,P1[nk+1]
+    double *wk = irfw;            // IRF work space: T[3nk], P0,Q0,P1[nk+1]
     for (int i = tid; i < nt; i += kLikeBlock) { st[i] = tsteps[ds.t_off + i]; sy[i] = sig[ds.sig_off + i]; }
     __syncthreads();
     for (int i = tid; i < nt - 1; i += kLikeBlock) sb[i] = (sy[i + 1] - sy[i]) / (st[i + 1] - st[i]);
@@ -417,7 +412,7 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
         const int nk = set.nk[ds.irf];
         const double *Tg = tables + set.off[ds.irf];
         double *T = wk, *P0 = T + 3 * nk, *Q0 = P0 + (nk + 1), *P1 = Q0 + (nk + 1);
-        int *jlo = reinterpret_cast<int *>(P1 + (nk + 1)), *jhi = jlo + nt;
+        int *jlo = reinterpret_cast<int *>(su2 + n_exp), *jhi = jlo + nt;  // run table, 2*nt ints
         for (int i = tid; i < 3 * nk; i += kLikeBlock) T[i] = Tg[i];
         __syncthreads();
         if (tid < 3) {  // prefix sums of the moment table (sequential: same rounding every time)
@@ -579,6 +574,37 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
                 ll[sidx * nT + j] = tot;
             }
         }
+    }
+}
+
+// One 768-thread block per (chain, measurement) while the per-sample arrays fit in LDS (GWORK = false:
+// 48 bytes per sample, 3400 samples in 160 KB next to a 189-tap IRF).  Longer traces -- real TRPL files
+// run to tens of thousands of samples, and the reference has no limit (trial_move_evaluation.py:96-158)
+// -- keep only the IRF work space in LDS and put the per-sample arrays in a per-block slab of global
+// memory (GWORK = true; L2-resident, written and read by this block only), blocks striding over the
+// traces.
+template <bool GWORK>
+__global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_desc *__restrict__ descs,
+                                                            const double *__restrict__ sig,
+                                                            const double *__restrict__ tsteps,
+                                                            const double *__restrict__ exp_t,
+                                                            const double *__restrict__ exp_y,
+                                                            const double *__restrict__ exp_u,
+                                                            const double *__restrict__ temps, int nT, int max_nt,
+                                                            const double *__restrict__ tables, IrfTableSet set,
+                                                            double neg_frac_tol, double *__restrict__ ll, int64_t B,
+                                                            double *__restrict__ gwork)
+{
+    extern __shared__ double smem[];
+    __shared__ double red_v[kLikeWaves];
+    __shared__ int64_t red_i[kLikeWaves];
+    __shared__ int s_cnt[2];
+    double *work = GWORK ? gwork + (size_t)blockIdx.x * 6 * (size_t)max_nt : smem;
+    double *irfw = GWORK ? smem : smem + 6 * (size_t)max_nt;
+    for (int64_t sidx = blockIdx.x; sidx < B; sidx += gridDim.x) {
+        loglik_trace(descs[sidx], sidx, sig, tsteps, exp_t, exp_y, exp_u, temps, nT, max_nt, tables, set, neg_frac_tol,
+                     ll, work, irfw, red_v, red_i, s_cnt);
+        __syncthreads();
     }
 }
 

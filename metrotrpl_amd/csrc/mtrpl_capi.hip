@@ -33,7 +33,7 @@ struct Slab {
 struct mtrpl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    SolveTuning tune{0.1, 3e-9, 3e-10, 1e-11, 1e-4, 2000000, 0.03, 8, 4.0, 3.0, 1, 0.5, 16.0, 1.2, 80, 1.2, 1.0, 1.0, 1.0, 10.0, 0.5};
+    SolveTuning tune{0.1, 3e-9, 3e-10, 1e-11, 0.0, 1e-4, 2000000, 0.03, 8, 4.0, 3.0, 1, 0.5, 16.0, 1.2, 80, 1.2, 1.0, 1.0, 1.0, 10.0, 0.5};
     std::string err;
     // IRF tables resident on the device (mtrpl_irf_tables_upload)
     double *d_irf_tab = nullptr;
@@ -47,6 +47,7 @@ struct mtrpl_ctx {
     size_t scratch_cap[kScratch] = {};
     int kernel_variant = 0;  // see include/metrotrpl_amd.h
     int precision = 64;      // 64: fp64 (the product); 32: the fp32 build of the team kernel (precision sweep only)
+    size_t like_lds_attr = 64 * 1024;  // dynamic-LDS limit the likelihood kernel has been raised to
     int pair_max_batch = 512;  // kernel_variant 0: launches up to this many solves use the wave-pair kernel
 };
 
@@ -116,8 +117,7 @@ __device__ inline void rhs_probe(BK &bk, const double *par, const double *dxs, c
     constexpr int R = BK::R, V = BK::V;
     const int L = nx, S = (BK::TRAPS ? 4 : 3) * nx + 1;
     const int oP = (BK::TRAPS ? 2 : 1) * L, oE = (BK::TRAPS ? 3 : 2) * L;
-    bk.p = make_par<double>(par + 16 * s, dxs[s]);
-    bk.L = L;
+    bk.set_problem(make_par<double>(par + 16 * s, dxs[s]), L);
     double yl[V], fl[V], zs[V];
     load_state(bk, y + s * S, L, yl, 1.0);
 #pragma unroll
@@ -177,8 +177,7 @@ __device__ inline void newton_probe(BK &bk, const double *par, const double *dxs
 {
     constexpr int R = BK::R, V = BK::V;
     const int L = nx, S = 3 * nx + 1;
-    bk.p = make_par<double>(par + 16 * s, dxs[s]);
-    bk.L = L;
+    bk.set_problem(make_par<double>(par + 16 * s, dxs[s]), L);
     double yl[V], bl[V], xl[V], zs[V];
     load_state(bk, y + s * S, L, yl, 1.0);
     load_state(bk, b + s * S, L, bl, 0.0);
@@ -399,6 +398,7 @@ struct OptI { const char *key; int SolveTuning::*m; };
 const OptD kOptD[] = {
     {"rtol_scale", &SolveTuning::rtol_scale}, {"rtol_cap", &SolveTuning::rtol_cap},
     {"rtol_floor", &SolveTuning::rtol_floor}, {"rtol_min", &SolveTuning::rtol_min},
+    {"rtol_force", &SolveTuning::rtol_force},
     {"atol_rel", &SolveTuning::atol_rel}, {"newton_tol", &SolveTuning::newton_tol},
     {"rate_first_safety", &SolveTuning::rate_first_safety}, {"e_weight", &SolveTuning::e_weight},
     {"trts_rtol_factor", &SolveTuning::trts_rtol_factor}, {"amp_ref", &SolveTuning::amp_ref},

@@ -13,6 +13,7 @@
 // nodes over lanes / waves and everything that needs neighbour or whole-grid data:
 //
 //   BK::real, BK::R (nodes per thread), BK::V (values per thread = 3R std / 4R traps), BK::TRAPS
+//   bk.set_problem(par, L)          model parameters and grid size of this solve
 //   bk.node(r)                      global node index of slot r of this thread
 //   bk.publish(y, zs)               make this thread group's boundary state visible to rhs()/build()
 //                                   of the neighbouring group (no-op where shuffles reach everything)
@@ -38,6 +39,8 @@
         acc += now_ - tlast_;                                         \
         tlast_ = now_;                                                \
     } while (0)
+#elif defined(MTRPL_MARKS)  // analysis build: phase boundaries as comments in the assembly listing
+#define MTRPL_STAMP(acc) asm volatile("; MARK " #acc)
 #else
 #define MTRPL_STAMP(acc) do { } while (0)
 #endif
@@ -60,6 +63,7 @@ struct SolveTuning {
     double rtol_cap;    // upper end of the internal rtol: the accuracy contract is the converged answer
     double rtol_floor;  // the policy factors (TRTS, tauP/tauN) never tighten below this ...
     double rtol_min;    // ... but a caller's own RTOL does, down to this noise floor (then status 2)
+    double rtol_force;  // > 0: internal rtol = exactly this for every solve (tolerance sweeps); 0: the policy
     double atol_rel;    // internal atol = min(rtol_int * atol_rel * max(N0, P0 over the film), desc.atol)
     int max_steps;
     double newton_tol;  // <= 0: SciPy's rule max(10 eps/rtol, min(0.03, sqrt(rtol))); else this value
@@ -193,8 +197,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
     constexpr bool TRAPS = BK::TRAPS;
     const int L = ds.nx, nt = ds.nt, meas = ds.meas;
     const double dx = ds.thickness / (double)L;  // sim_utils.py:265
-    bk.p = make_par<real>(ds.par, dx);
-    bk.L = L;
+    bk.set_problem(make_par<real>(ds.par, dx), L);
     const ParT<real> &p = bk.p;
     const double *ts = tsteps + ds.t_off;
     const real hmax = tune.honor_hmax ? (real)ds.hmax : big<real>();
@@ -269,6 +272,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             r_ = base;  // the caller asked for more than the policy would ever do
             if (r_ < tune.rtol_min) { r_ = tune.rtol_min; tol_clamped = true; }
         }
+        if (tune.rtol_force > 0.0) { r_ = tune.rtol_force; tol_clamped = false; }
         rtol = (real)r_;
         // desc.atol (solver units, nm^-3) bounds the absolute term from above: the default 1e-10 is far
         // looser than the relative rule and changes nothing; a smaller ATOL tightens the deep tail.
@@ -361,11 +365,12 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
     for (int v = 0; v < V; ++v) acp[v] = (real)0;
 
 #ifdef MTRPL_STAMPS
-    unsigned long long tlast_ = __builtin_amdgcn_s_memtime(), ph_sel = 0, ph_pred = 0, ph_fac = 0, ph_newt = 0,
-                       ph_err = 0, ph_upd = 0, ph_dense = 0;
+    // controller vector work | factorisation | rhs | linear re-solve | reductions + publishes | Newton glue | dense output
+    unsigned long long tlast_ = __builtin_amdgcn_s_memtime(), ph_ctl = 0, ph_fac = 0, ph_rhs = 0, ph_app = 0,
+                       ph_red = 0, ph_glue = 0, ph_dense = 0;
 #endif
     while (io < nt) {
-        MTRPL_STAMP(ph_sel);
+        MTRPL_STAMP(ph_ctl);
         if (n_steps >= tune.max_steps) { st = MTRPL_SOLVE_STOPPED_EARLY; break; }
         bool accepted = false;
         real acor[V], yn[V], isc[V];  // isc: 1/(atol + rtol*|y_predicted|), the error weights of this step
@@ -374,7 +379,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         int attempts = 0;
         while (!accepted) {
             if (++attempts > 60 || !(h > (real)1e-13 * fmax(t, (real)1e-3))) { st = MTRPL_SOLVE_STOPPED_EARLY; break; }
-            MTRPL_STAMP(ph_err);
+            MTRPL_STAMP(ph_ctl);
             // the order / step-size selection runs after this step if it is accepted with n_equal >= order:
             // its two grid sums then travel with the Newton norms instead of costing a reduction of their own
             const bool will_select = n_equal >= order;
@@ -385,16 +390,17 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             const real early_scale = (tune.early_factor > 1.0 && t + h <= early_until) ? early_inv : (real)1;
 #pragma unroll
             for (int v = 0; v < V; ++v) isc[v] = ctl_rcp(atol + rtol_of(v) * fabs(z[0][v])) * early_scale;
-            MTRPL_STAMP(ph_pred);
+            MTRPL_STAMP(ph_ctl);
             // simplified Newton on acor:  (I - h l0 J) dx = h f(y) - z[1] - acor,  y = z[0] + l0 acor
             bool converged = false, fresh = false;
             int n_iter = 0;
             while (!converged) {
 #pragma unroll
                 for (int v = 0; v < V; ++v) { acor[v] = (real)0; yn[v] = z[0][v]; zs[v] = z[1][v]; }
+                MTRPL_STAMP(ph_glue);
                 bk.publish(yn, zs);
+                MTRPL_STAMP(ph_red);
                 if (!have_fac) {
-                    MTRPL_STAMP(ph_newt);
                     // the analytic Jacobian is evaluated inside the factorisation: always at the predictor
                     bk.build(z[0], c, h);
                     MTRPL_STAMP(ph_fac);
@@ -408,12 +414,16 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                 real dn_old = (real)0;
                 for (int k = 0; k < 4; ++k) {
                     n_iter = k + 1;
+                    MTRPL_STAMP(ph_glue);
                     bk.rhs(yn, f);
+                    MTRPL_STAMP(ph_rhs);
                     n_rhs++;
                     real b[V], dxv[V];
 #pragma unroll
                     for (int v = 0; v < V; ++v) b[v] = h * f[v] - zs[v];
+                    MTRPL_STAMP(ph_glue);
                     bk.apply(b, dxv);
+                    MTRPL_STAMP(ph_app);
                     // the update is applied before the convergence decision (a rejected iterate is simply
                     // discarded): the norms of the increment and of the whole correction, and the boundary
                     // state the next rhs() needs, then share one reduction
@@ -442,13 +452,16 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                             const real a_ = (acor[v] - acp[v]) * isc[v];
                             s4[3] += a_ * a_;
                         }
+                        MTRPL_STAMP(ph_glue);
                         bk.template reduce<4>(s4, yn, zs);
                     } else {
                         real s2[2] = {s4[0], s4[1]};
+                        MTRPL_STAMP(ph_glue);
                         bk.template reduce<2>(s2, yn, zs);
                         s4[0] = s2[0];
                         s4[1] = s2[1];
                     }
+                    MTRPL_STAMP(ph_red);
                     const real dn = norm_sqrt(s4[0] * inv_S);
                     if (!(dn < big<real>())) break;  // NaN / inf
                     real rate = rate_prev;
@@ -491,7 +504,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                 have_fac = false;
                 continue;
             }
-            MTRPL_STAMP(ph_newt);
+            MTRPL_STAMP(ph_glue);
             // 0.9 * (2*4 + 1) / (2*4 + n_iter), n_iter = 1..4
             safety = (n_iter == 1) ? (real)0.9 : ((n_iter == 2) ? (real)0.81 : ((n_iter == 3) ? (real)(8.1 / 11.0) : (real)0.675));
             if (dsm > (real)1) {
@@ -507,14 +520,14 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             }
         }
         if (!accepted) break;
-        MTRPL_STAMP(ph_err);
+        MTRPL_STAMP(ph_ctl);
         const bool selecting = n_equal >= order;  // = will_select of the accepted attempt
         n_steps++;
         n_equal++;
         since_rej++;
         t += h;
         MTRPL_ORDER_SWITCH(order, (nq_correct<K, V>(z, acor)))
-        MTRPL_STAMP(ph_upd);
+        MTRPL_STAMP(ph_ctl);
         // dense output (Taylor polynomial of the Nordsieck array), forward_solver.py:167
         const real ih = frcp(h);
         while (io < nt) {
@@ -590,8 +603,8 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             s[4] = n_rej; s[5] = n_nfail; s[6] = order;
             s[7] = (int32_t)((__builtin_amdgcn_s_memtime() - clk0_) >> 4);  // residency of this solve, 16-tick units
 #ifdef MTRPL_STAMPS
-            s[1] = (int)(ph_sel >> 10); s[2] = (int)(ph_pred >> 10); s[3] = (int)(ph_fac >> 10);
-            s[4] = (int)(ph_newt >> 10); s[5] = (int)(ph_err >> 10); s[6] = (int)(ph_upd >> 10);
+            s[1] = (int)(ph_ctl >> 10); s[2] = (int)(ph_fac >> 10); s[3] = (int)(ph_rhs >> 10);
+            s[4] = (int)(ph_app >> 10); s[5] = (int)(ph_red >> 10); s[6] = (int)(ph_glue >> 10);
             s[7] = (int)(ph_dense >> 10);
 #endif
         }

@@ -14,7 +14,7 @@ r = refs[1e-12]; m = np.abs(r) >= 1e-4 * abs(r[0])
 for rt in refs: print("oracle", rt, "vs 1e-12: %.2e" % np.max(np.abs(refs[rt] - r)[m] / np.abs(r[m])))
 ctx = L.default_context()
 for cap in (2e-8, 1e-8, 5e-9, 3e-9):
-    ctx.set_option("rtol_cap", cap); ctx.set_option("rtol_floor", cap)
+    ctx.set_option("rtol_force", cap)
     sig, st, stats = batch.solve_batch(e["states"][k:k+1], ix, un, e["iniPar"][k:k+1], e["thickness"][k], 128, e["tSteps"], return_stats=True)
     err = np.abs(sig[0] - r)[m] / np.abs(r[m])
     print("gpu rtol", cap, "err max %.2e at sample %d of %d, steps %d" % (err.max(), err.argmax(), m.sum(), stats[0, 0]), "err[::25]", np.array2string(err[::25], precision=1))

@@ -19,7 +19,7 @@ if __name__ == "__main__":
     from metrotrpl_amd import batch, _lib as L
     ctx = L.default_context()
     for rc in (5e-9, 3e-9, 2e-9, 1.5e-9):
-        ctx.set_option("rtol_cap", rc); ctx.set_option("rtol_floor", rc)
+        ctx.set_option("rtol_force", rc)
         sig, status, stats = batch.solve_batch(c["states"], ix, un, c["iniPar"], c["thickness"], c["nx"], c["tSteps"], return_stats=True)
         errs = []
         for k in range(N):

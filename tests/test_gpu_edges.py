@@ -53,9 +53,24 @@ def test_ragged_batch_matches_individual_calls():
     ctx.check(L.lib().mtrpl_solve_batch(ctx.handle, 5, d.ctypes.data_as(C.c_void_p), L.dptr(ini), 64, L.dptr(t_all),
                                         len(t_all), L.dptr(out), len(out), L.iptr(status), None))
     assert np.all(status == 0)
+    # The kernel is chosen per launch from the largest nx and the batch size (one wave per solve for nx <= 64,
+    # a wave pair up to 128), so a solve packed next to a larger one may run on a different -- equally
+    # converged -- distribution of the same integrator: agreement far inside the 1e-6 gate, not bitwise ...
     for k in range(5):
-        np.testing.assert_array_equal(out[t_off[k]:t_off[k] + len(grids[k])], singles[k])
+        np.testing.assert_allclose(out[t_off[k]:t_off[k] + len(grids[k])], singles[k], rtol=2e-7)
     assert len(singles[2]) == 1 and singles[2][0] > 0  # nt = 1: just the t=0 sample
+    # ... and bitwise once the kernel is pinned: a solve does not depend on its batch mates
+    for variant in (2, 4):
+        ctx.set_option("kernel_variant", variant)
+        try:
+            out2 = np.empty(len(t_all))
+            ctx.check(L.lib().mtrpl_solve_batch(ctx.handle, 5, d.ctypes.data_as(C.c_void_p), L.dptr(ini), 64, L.dptr(t_all),
+                                                len(t_all), L.dptr(out2), len(out2), L.iptr(status), None))
+            k = 1  # the nx = 128 solve runs on the same kernel alone or in the batch
+            one = batch.solve_batch(s0[None, :], ix, un, [[1.92e12, 6e4, 1]], thick[k], nxs[k], grids[k], meas=meas[k])[0]
+        finally:
+            ctx.set_option("kernel_variant", 0)
+        np.testing.assert_array_equal(out2[t_off[k]:t_off[k] + len(grids[k])], one)
 
 
 def test_descriptor_validation_errors():

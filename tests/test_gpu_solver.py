@@ -265,7 +265,7 @@ def test_every_backend_lands_on_the_converged_traces():
         m = np.abs(ref) >= 1e-4 * abs(ref[0])
         for variant in variants:
             assert np.max(np.abs(out[variant][k][m] - ref[m]) / np.abs(ref[m])) <= 1e-6, (variant, k)
-    assert not np.array_equal(out[2], out[4]) and not np.array_equal(out[2], out[1])
+    assert not np.array_equal(out[2], out[4])  # (the one-wave team kernel reproduces the wave kernel bit for bit)
 
 
 def test_census_subset_within_gate():

@@ -135,12 +135,11 @@ def test_fp32_build_of_the_team_kernel(gold):
     1e-6 gate, which is why fp64 is the product (tools/config5_sweep.py has the full sweep)."""
     from metrotrpl_amd import _lib as L
     ctx = L.default_context()
-    saved = {k: ctx.get_option(k) for k in ("rtol_cap", "rtol_floor", "max_steps", "atol_rel")}
+    saved = {k: ctx.get_option(k) for k in ("rtol_force", "max_steps", "atol_rel")}
     try:
         ctx.set_option("precision", 32)
         assert ctx.get_option("precision") == 32
-        ctx.set_option("rtol_cap", 1e-4)
-        ctx.set_option("rtol_floor", 1e-4)
+        ctx.set_option("rtol_force", 1e-4)
         ctx.set_option("atol_rel", 1e-2)  # fp32 needs the looser absolute floor: Newton stalls on rounding noise otherwise
         ctx.set_option("max_steps", 100000)
         for key in ("cfg5_thick_pl__tight", "cfg5_thin_trts__tight", "cfg2_0__tight"):

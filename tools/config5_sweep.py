@@ -18,7 +18,7 @@ refs, NS = z["refs"], int(z["n_states"])
 c = W.config5(NS)
 ix, un = W.indexes(), W.units()
 ctx = L.default_context()
-defaults = {k: ctx.get_option(k) for k in ("rtol_cap", "rtol_floor", "atol_rel", "max_steps")}
+defaults = {k: ctx.get_option(k) for k in ("rtol_force", "rtol_cap", "rtol_floor", "atol_rel", "max_steps")}
 ctx.set_option("max_steps", 100000)  # bounds a non-converging fp32 run: it stops early and is counted as failed
 meas = np.array(c["meas"])
 rows = []
@@ -32,8 +32,7 @@ for precision, atol_rel in ((64, 1e-4), (32, 1e-4), (32, 1e-2), (64, None)):
                 ctx.set_option(k, v)
             atol_rel = defaults["atol_rel"]
         else:
-            ctx.set_option("rtol_cap", rtol)
-            ctx.set_option("rtol_floor", rtol)
+            ctx.set_option("rtol_force", rtol)
         t0 = time.time()
         sig, status, stats = batch.solve_batch(c["states"], ix, un, c["iniPar"], c["thickness"], c["nx"], c["tSteps"],
                                                meas=c["meas"], return_stats=True)

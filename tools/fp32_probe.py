@@ -15,7 +15,7 @@ for prec in (32, 64):
         th, nx, hmax, _, _, min_y = gold[key + "__geom"]
         idx = {n: i for i, n in enumerate(names.split(","))}
         for rtol in (1e-3, 1e-4, 1e-5, 1e-6):
-            ctx.set_option("rtol_cap", rtol); ctx.set_option("rtol_floor", rtol)
+            ctx.set_option("rtol_force", rtol)
             for aw in (1e-4, 1e-2):
                 ctx.set_option("atol_rel", aw)
                 sig, status, stats = batch.solve_batch(gold[key + "__state"][None, :], idx, gold[key + "__units"], gold[key + "__iniPar"][None, :],

@@ -1,14 +1,38 @@
-"""Phase breakdown from the -DMTRPL_STAMPS diagnostic build (dev tool)."""
-import sys, os
-os.environ["MTRPL_LIB_PATH"] = "/root/repo/metrotrpl_amd/lib/libmetrotrpl_amd_stamps.so"
-import numpy as np
-sys.path.insert(0, "/root/repo")
-from metrotrpl_amd import batch, workloads as W
-c = W.config2(1024); ix, un = W.indexes(), W.units()
-for rep in range(2):
-    sig, status, st = batch.solve_batch(c["states"], ix, un, c["iniPar"], c["thickness"], c["nx"], c["tSteps"], return_stats=True)
-names = ["steps", "sel+chgD", "pred", "build_fac", "newton", "err+reject", "D update", "dense out"]
-tot = st[:, 1:].sum(axis=1).astype(float)
-print("mean steps", st[:, 0].mean(), "mean total kcycles", tot.mean(), "max", tot.max())
-for k in range(1, 8):
-    print(f"{names[k]:12s}: {st[:,k].mean():9.0f} kcyc  {100*st[:,k].sum()/tot.sum():5.1f}%   per step {1024*st[:,k].mean()/st[:,0].mean():7.0f} cyc")
+"""Phase breakdown of a solve from the -DMTRPL_STAMPS diagnostic build (dev tool; the product library has
+no stamps).  Builds metrotrpl_amd/lib/libmetrotrpl_amd_stamps.so if needed.
+usage: python tools/stamps.py [--variant 2] [--batch 1024]"""
+import argparse
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(REPO, "metrotrpl_amd", "lib", "libmetrotrpl_amd_stamps.so")
+if not os.path.exists(LIB) or os.environ.get("MTRPL_STAMPS_REBUILD"):
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                           "-DMTRPL_STAMPS", "-o", LIB, os.path.join(REPO, "metrotrpl_amd", "csrc", "mtrpl_capi.hip")])
+os.environ["MTRPL_LIB_PATH"] = LIB
+import numpy as np  # noqa: E402
+sys.path.insert(0, REPO)
+from metrotrpl_amd import _lib as L, batch, workloads as W  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--variant", default="2")
+ap.add_argument("--batch", type=int, default=1024)
+a = ap.parse_args()
+c = W.config2(a.batch)
+ix, un = W.indexes(), W.units()
+ctx = L.default_context()
+names = ["steps", "controller", "factorise", "rhs", "re-solve", "reduce+publish", "newton glue", "dense out"]
+for variant in [int(v) for v in a.variant.split(",")]:
+    ctx.set_option("kernel_variant", variant)
+    for rep in range(2):
+        sig, status, st = batch.solve_batch(c["states"], ix, un, c["iniPar"], c["thickness"], c["nx"], c["tSteps"],
+                                            return_stats=True)
+    tot = st[:, 1:].sum(axis=1).astype(float)
+    print(f"variant {variant} B {a.batch}: mean steps {st[:, 0].mean():.0f}, mean total {tot.mean():.0f} kcycles, max {tot.max():.0f}; "
+          f"per step {1024 * tot.mean() / st[:, 0].mean():.0f} cycles")
+    for k in range(1, 8):
+        print(f"  {names[k]:15s}: {st[:, k].mean():9.0f} kcyc  {100 * st[:, k].sum() / tot.sum():5.1f}%   per step "
+              f"{1024 * st[:, k].mean() / st[:, 0].mean():7.0f} cyc")
+ctx.set_option("kernel_variant", 0)
