@@ -123,17 +123,17 @@ struct PairBackend {
         n_pend = 0;
     }
 
-    __device__ inline void publish(const double (&y)[V], const double (&zs)[V])
+    __device__ inline void publish(const double (&y)[V], const double (&zE)[R])
     {
         if (W == 1) return;
-        const double mine[8] = {y[0], y[1], y[2], zs[2], pend[0], pend[1], pend[2], pend[3]};
+        const double mine[8] = {y[0], y[1], y[2], zE[0], pend[0], pend[1], pend[2], pend[3]};
         double th[8];
         xchg<8>(mine, th);
         nbN = th[0]; nbP = th[1]; nbE = th[2]; nbZ = th[3];
         emit_pending(th[4], th[5], th[6], th[7]);
     }
     template <int NS>
-    __device__ inline void reduce(double (&s)[NS], const double (&y)[V], const double (&zs)[V])
+    __device__ inline void reduce(double (&s)[NS], const double (&y)[V], const double (&zE)[R])
     {
         static_assert(NS <= 4, "record holds 4 sums + the boundary state");
 #pragma unroll
@@ -145,7 +145,7 @@ struct PairBackend {
         for (int k = 0; k < KD; ++k) mine[k] = 0.0;
 #pragma unroll
         for (int k = 0; k < NS; ++k) mine[k] = s[k];
-        mine[NS] = y[0]; mine[NS + 1] = y[1]; mine[NS + 2] = y[2]; mine[NS + 3] = zs[2];
+        mine[NS] = y[0]; mine[NS + 1] = y[1]; mine[NS + 2] = y[2]; mine[NS + 3] = zE[0];
         xchg<KD>(mine, th);
 #pragma unroll
         for (int k = 0; k < NS; ++k) s[k] = uniform(mine[k] + th[k]);

@@ -92,10 +92,10 @@ struct TeamBackend {
     }
 
     // ---- whole-grid primitives ----
-    __device__ inline void publish(const real (&)[V], const real (&)[V]) {}
+    __device__ inline void publish(const real (&)[V], const real (&)[R]) {}
     // sums over all threads of the team; every thread gets bitwise the same result
     template <int NS>
-    __device__ inline void reduce(real (&s)[NS], const real (&)[V], const real (&)[V])
+    __device__ inline void reduce(real (&s)[NS], const real (&)[V], const real (&)[R])
     {
         static_assert(NS <= 4, "rbuf holds 4 sums per wave");
 #pragma unroll

@@ -60,9 +60,9 @@ struct WaveBackend {
     }
 
     // ---- whole-grid primitives: everything is inside one wave ----
-    __device__ inline void publish(const double (&)[V], const double (&)[V]) {}
+    __device__ inline void publish(const double (&)[V], const double (&)[R]) {}
     template <int NS>
-    __device__ inline void reduce(double (&s)[NS], const double (&)[V], const double (&)[V])
+    __device__ inline void reduce(double (&s)[NS], const double (&)[V], const double (&)[R])
     {
 #pragma unroll
         for (int k = 0; k < NS; ++k) s[k] = uniform(wave_sum_ctl(s[k]));

@@ -48,7 +48,8 @@ struct mtrpl_ctx {
     int kernel_variant = 0;  // see include/metrotrpl_amd.h
     int precision = 64;      // 64: fp64 (the product); 32: the fp32 build of the team kernel (precision sweep only)
     size_t like_lds_attr = 64 * 1024;  // dynamic-LDS limit the likelihood kernel has been raised to
-    int pair_max_batch = 512;  // kernel_variant 0: launches up to this many solves use the wave-pair kernel
+    int pair_max_batch = 0;  // kernel_variant 0: launches up to this many solves use the wave-pair kernel (0: never --
+                             // measured: its exchanges cost what the halved per-lane work saves)
 };
 
 #define HIP_TRY(ctx, expr)                                                                   \
@@ -118,11 +119,11 @@ __device__ inline void rhs_probe(BK &bk, const double *par, const double *dxs, c
     const int L = nx, S = (BK::TRAPS ? 4 : 3) * nx + 1;
     const int oP = (BK::TRAPS ? 2 : 1) * L, oE = (BK::TRAPS ? 3 : 2) * L;
     bk.set_problem(make_par<double>(par + 16 * s, dxs[s]), L);
-    double yl[V], fl[V], zs[V];
+    double yl[V], fl[V], zE[R];
     load_state(bk, y + s * S, L, yl, 1.0);
 #pragma unroll
-    for (int v = 0; v < V; ++v) zs[v] = 0.0;
-    bk.publish(yl, zs);
+    for (int r = 0; r < R; ++r) zE[r] = 0.0;
+    bk.publish(yl, zE);
     bk.rhs(yl, fl);
     double *fs = dy + s * S;
 #pragma unroll
@@ -178,16 +179,15 @@ __device__ inline void newton_probe(BK &bk, const double *par, const double *dxs
     constexpr int R = BK::R, V = BK::V;
     const int L = nx, S = 3 * nx + 1;
     bk.set_problem(make_par<double>(par + 16 * s, dxs[s]), L);
-    double yl[V], bl[V], xl[V], zs[V];
+    double yl[V], bl[V], xl[V], zE[R];
     load_state(bk, y + s * S, L, yl, 1.0);
     load_state(bk, b + s * S, L, bl, 0.0);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (bk.node(r) == 0) bl[2 * R + r] = 0.0;  // the E_0 row of I - cJ is an identity row
-        zs[r] = 0.0; zs[R + r] = 0.0;
-        zs[2 * R + r] = -bl[2 * R + r];  // with h = 0 the neighbouring group reads b_E of its boundary edge from here
+        zE[r] = -bl[2 * R + r];  // with h = 0 the neighbouring group reads b_E of its boundary edge from here
     }
-    bk.publish(yl, zs);
+    bk.publish(yl, zE);
     bk.build(yl, cs[s], 0.0);
     bk.apply(bl, xl);
 #pragma unroll
@@ -473,8 +473,7 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
     }
     // std model, nx <= 128: the register-resident backends.
     //   wave (2):  one wave per solve, two nodes per lane -- most solves per second in a full launch
-    //   pair (4):  two waves per solve, one node per lane, blocks in registers -- shortest solve when the
-    //              launch leaves SIMDs idle (B <= pair_max_batch: 2 B waves on 1024 SIMDs)
+    //   pair (4):  two waves per solve, one node per lane, blocks in registers (opt-in: pair_max_batch)
     //   pair (5):  the same with every block in LDS and a register budget for two waves per SIMD
     int variant = ctx->kernel_variant;
     if (variant == 0) variant = (!traps && max_nx <= 128 && B <= ctx->pair_max_batch) ? 4 : 2;

@@ -15,13 +15,14 @@
 //   BK::real, BK::R (nodes per thread), BK::V (values per thread = 3R std / 4R traps), BK::TRAPS
 //   bk.set_problem(par, L)          model parameters and grid size of this solve
 //   bk.node(r)                      global node index of slot r of this thread
-//   bk.publish(y, zs)               make this thread group's boundary state visible to rhs()/build()
+//   bk.publish(y, zE)               make this thread group's boundary state (y and, per node slot, zE = z1_E + acor_E)
+//                                   visible to rhs()/build()/apply()
 //                                   of the neighbouring group (no-op where shuffles reach everything)
 //   bk.rhs(y, f)                    f = dy/dt                              (forward_solver.py:332-418)
 //   bk.build(y, c, h)               factorise I - c*J(y)
 //   bk.apply(b, x)                  x = (I - c*J)^-1 b with the kept factors
-//   bk.reduce<NS>(s, y, zs)         s[k] <- sum over the whole grid, identical in every thread;
-//                                   doubles as publish(y, zs) for the next rhs()
+//   bk.reduce<NS>(s, y, zE)         s[k] <- sum over the whole grid, identical in every thread;
+//                                   doubles as publish(y, zE) for the next rhs()
 //   bk.scan_excl(v), bk.max_all(v)  exclusive prefix over the threads before this one / maximum
 //   bk.out_begin / out_sample / out_finish   emission of the output samples (scale, min_y clamp)
 //   bk.leader()                     the one thread that writes status / stats
@@ -305,10 +306,10 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
     bk.out_sample(0, sig_partial(y));
 
     real z[6][V];
-    real f[V], w[V], zs[V];
+    real f[V], w[V], zE[R];
 #pragma unroll
-    for (int v = 0; v < V; ++v) zs[v] = (real)0;
-    bk.publish(y, zs);
+    for (int r = 0; r < R; ++r) zE[r] = (real)0;
+    bk.publish(y, zE);
     bk.rhs(y, f);
     n_rhs++;
 
@@ -320,7 +321,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             s3[0] = (real)0;
 #pragma unroll
             for (int k = 0; k < V; ++k) s3[0] += vv[k] * vv[k];
-            bk.template reduce<1>(s3, y, zs);
+            bk.template reduce<1>(s3, y, zE);
             return norm_sqrt(s3[0] * inv_S);
         };
 #pragma unroll
@@ -333,7 +334,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         real y1[V], f1[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) y1[v] = y[v] + h0 * f[v];
-        bk.publish(y1, zs);
+        bk.publish(y1, zE);
         bk.rhs(y1, f1);
         n_rhs++;
 #pragma unroll
@@ -396,9 +397,11 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             int n_iter = 0;
             while (!converged) {
 #pragma unroll
-                for (int v = 0; v < V; ++v) { acor[v] = (real)0; yn[v] = z[0][v]; zs[v] = z[1][v]; }
+                for (int v = 0; v < V; ++v) { acor[v] = (real)0; yn[v] = z[0][v]; }
+#pragma unroll
+                for (int r = 0; r < R; ++r) zE[r] = z[1][2 * R + r];
                 MTRPL_STAMP(ph_glue);
-                bk.publish(yn, zs);
+                bk.publish(yn, zE);
                 MTRPL_STAMP(ph_red);
                 if (!have_fac) {
                     // the analytic Jacobian is evaluated inside the factorisation: always at the predictor
@@ -420,7 +423,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                     n_rhs++;
                     real b[V], dxv[V];
 #pragma unroll
-                    for (int v = 0; v < V; ++v) b[v] = h * f[v] - zs[v];
+                    for (int v = 0; v < V; ++v) b[v] = h * f[v] - z[1][v] - acor[v];
                     MTRPL_STAMP(ph_glue);
                     bk.apply(b, dxv);
                     MTRPL_STAMP(ph_app);
@@ -434,10 +437,11 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                         s4[0] += wv * wv;
                         acor[v] += dxv[v];
                         yn[v] += el0 * dxv[v];
-                        zs[v] = z[1][v] + acor[v];
                         const real av = acor[v] * isc[v];
                         s4[1] += av * av;
                     }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) zE[r] = z[1][2 * R + r] + acor[2 * R + r];
                     if (will_select) {
                         // stode: ddn from the last Nordsieck row (after the correction), dup from acor - acor_prev
                         switch (order) {
@@ -453,11 +457,11 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                             s4[3] += a_ * a_;
                         }
                         MTRPL_STAMP(ph_glue);
-                        bk.template reduce<4>(s4, yn, zs);
+                        bk.template reduce<4>(s4, yn, zE);
                     } else {
                         real s2[2] = {s4[0], s4[1]};
                         MTRPL_STAMP(ph_glue);
-                        bk.template reduce<2>(s2, yn, zs);
+                        bk.template reduce<2>(s2, yn, zE);
                         s4[0] = s2[0];
                         s4[1] = s2[1];
                     }

@@ -1,59 +1,108 @@
-// microbench.hip -- cycles per call of the building blocks of one integration step, one wave per
-// SIMD as in the solve kernel (dev tool).  hipcc --offload-arch=gfx950 -O3 -std=c++17 -o microbench
+// microbench.hip -- cycles per call of the building blocks of one integration step for each solver
+// backend, one solve per workgroup as in the solve kernels (dev tool).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gpurun_out/microbench tools/microbench.hip && gpurun_out/microbench
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "../metrotrpl_amd/csrc/solve_kernel.hpp"
+#include "../metrotrpl_amd/csrc/backend_wave.hpp"
+#include "../metrotrpl_amd/csrc/backend_pair.hpp"
 using namespace mtrpl;
 
-template <int WHAT>
-__global__ __launch_bounds__(64, 1) void bench(const double *par, double *out, long long *cyc, int iters)
+enum { RHS = 0, APPLY, BUILD, REDUCE2, REDUCE4, PUBLISH, PREDICT, CORRECT, DENSE, NWHAT };
+static const char *kNames[] = {"rhs", "apply", "build", "reduce<2>", "reduce<4>", "publish", "predict(5)", "correct(5)", "dense+out"};
+
+template <class BK, int WHAT>
+__device__ inline void body(BK &bk, double *out, long long *cyc, int iters)
 {
-    constexpr int R = 2, V = 6;
-    const int lane = threadIdx.x, L = 128;
-    const Par p = make_par(par, 2000.0 / 128);
-    double y[V], f[V], w[V], D[8][V];
-    for (int v = 0; v < V; ++v) { y[v] = (v < 4) ? 1e-5 * (1.0 + 0.001 * lane + 0.01 * v) : 1e-6 * (lane - 32); w[v] = 0.1 * v + lane; }
-    for (int k = 0; k < 8; ++k) for (int v = 0; v < V; ++v) D[k][v] = y[v] * (k == 0 ? 1.0 : 1e-3 / (k + 1));
-    __shared__ double2 fac_lds[kFactorLdsBytes / 16];
-    Factors<R> F; F.lds = fac_lds;
-    build_factors(p, y, 0.1, lane, L, F);
-    double acc = 0.0;
-    int order = 5 - (iters & 0);  // runtime value
-    long long t0, t1;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
-    for (int it = 0; it < iters; ++it) {
-        if (WHAT == 0) { const double n_ = wnorm<V>(w, 1.0 / 385); acc += n_; for (int v = 0; v < V; ++v) w[v] = w[v] * 0.999 + n_ * 1e-3; }
-        if (WHAT == 1) { rhs_std<R>(p, y, f, lane, L); for (int v = 0; v < V; ++v) y[v] += f[v] * 1e-9; }
-        if (WHAT == 2) { double b[V], x[V]; for (int v = 0; v < V; ++v) b[v] = w[v]; apply_factors(F, b, x, lane, L); for (int v = 0; v < V; ++v) w[v] = w[v] * 0.5 + x[v] * 0.5; }
-        if (WHAT == 3) { double yp[V], psi[V]; MTRPL_ORDER_SWITCH(order, (ndf_predict<K, V>(D, yp, psi))) for (int v = 0; v < V; ++v) { D[1][v] += yp[v] * 1e-9; D[2][v] += psi[v] * 1e-9; } }
-        if (WHAT == 4) { MTRPL_ORDER_SWITCH(order, (ndf_update<K, V>(D, w))) for (int v = 0; v < V; ++v) w[v] = D[0][v] * 1e-3; }
-        if (WHAT == 5) { double yq[V]; MTRPL_ORDER_SWITCH(order, (ndf_dense<K, V>(D, 1.0 + 1e-3 * it, 1.5, 1.0, 1.0, yq))) const double sg_ = signal_of<R>(p, yq, 0, lane, L, 1e23); acc += sg_; for (int v = 0; v < V; ++v) D[0][v] += sg_ * 1e-40; }
-        if (WHAT == 6) { build_factors(p, y, 0.1 + 1e-6 * it, lane, L, F); y[0] += F.cd * 1e-30; }
-        if (WHAT == 7) { change_D<V>(D, order, 1.0 + 1e-3 * (it & 7), lane); }
-        if (WHAT == 8) { double sm, sp; MTRPL_ORDER_SWITCH(order, (ndf_sel<K, V>(D, w, sm, sp))) acc += uniform(norm_sqrt(wave_sum(sm))) + uniform(norm_sqrt(wave_sum(sp))); for (int v = 0; v < V; ++v) { D[5][v] += acc * 1e-12; D[7][v] += acc * 1e-12; } }
-        if (WHAT == 9) { const double n_ = wave_sum(w[0]); acc += n_; w[0] = w[0] * 0.999 + n_ * 1e-3; }
+    constexpr int R = BK::R, V = BK::V;
+    double y[V], f[V], w[V], z[6][V], zE[R];
+    for (int r = 0; r < R; ++r) {
+        const int i = bk.node(r);
+        y[r] = 1e-5 * (1.0 + 0.001 * i);
+        y[R + r] = 1.2e-5 * (1.0 + 0.0007 * i);
+        y[2 * R + r] = 1e-6 * (i - 60);
+        zE[r] = 0.0;
     }
-    asm volatile("" :: "v"(acc), "v"(y[0]), "v"(y[3]), "v"(w[0]), "v"(w[5]), "v"(D[0][0]), "v"(D[1][0]), "v"(D[5][0]), "v"(D[7][5]) : "memory");
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+    for (int v = 0; v < V; ++v) { w[v] = 0.1 * v + 1e-3 * threadIdx.x; f[v] = 0.0; }
+    for (int k = 0; k < 6; ++k)
+        for (int v = 0; v < V; ++v) z[k][v] = y[v] * (k == 0 ? 1.0 : 1e-3 / (k + 1));
+    bk.publish(y, zE);
+    bk.build(y, 0.1, 0.1);
+    double acc = 0.0;
+    __shared__ double sink[1024];
+    bk.out_begin(sink, 0.0, 1.0);
+    long long t0, t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int it = 0; it < iters; ++it) {
+        if (WHAT == RHS) { bk.rhs(y, f); for (int v = 0; v < V; ++v) y[v] += f[v] * 1e-9; }
+        if (WHAT == APPLY) { double b[V], x[V]; for (int v = 0; v < V; ++v) b[v] = w[v]; bk.apply(b, x); for (int v = 0; v < V; ++v) w[v] = w[v] * 0.5 + x[v] * 0.5; }
+        if (WHAT == BUILD) { bk.build(y, 0.1 + 1e-6 * it, 0.1); y[0] += bk.cd * 1e-30; }
+        if (WHAT == REDUCE2) { double s[2] = {w[0] * w[0], w[1] * w[1]}; bk.template reduce<2>(s, y, zE); acc += s[0]; w[0] = w[0] * 0.999 + s[1] * 1e-9; }
+        if (WHAT == REDUCE4) { double s[4] = {w[0] * w[0], w[1] * w[1], w[2], w[0]}; bk.template reduce<4>(s, y, zE); acc += s[0] + s[3]; w[0] = w[0] * 0.999 + s[1] * 1e-9 + s[2] * 1e-12; }
+        if (WHAT == PUBLISH) { bk.publish(y, zE); y[0] += bk.p.dx * 1e-30; }
+        if (WHAT == PREDICT) { nq_predict<5, V>(z); for (int v = 0; v < V; ++v) z[5][v] = z[5][v] * 0.5 + 1e-12; }
+        if (WHAT == CORRECT) { nq_correct<5, V>(z, w); for (int v = 0; v < V; ++v) w[v] = z[0][v] * 1e-3; }
+        if (WHAT == DENSE) {
+            double yq[V];
+            nq_dense<5, V>(z, 0.5 + 1e-4 * (it & 15), yq);
+            double s = 0.0;
+            for (int r = 0; r < R; ++r) s += signal_density(bk.p, 0, yq[r], yq[R + r]);
+            bk.out_sample(it & 1023, s);
+            for (int v = 0; v < V; ++v) z[0][v] += 1e-30;
+        }
+    }
+    bk.out_finish();
+    asm volatile("" ::"v"(acc), "v"(y[0]), "v"(w[0]), "v"(z[0][0]), "v"(z[5][0]), "v"(f[0]) : "memory");
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
     double s = acc;
-    for (int v = 0; v < V; ++v) s += y[v] + w[v] + f[v] * 0 + D[3][v];
-    if (lane == 0) { out[blockIdx.x] = s; cyc[blockIdx.x] = t1 - t0; }
+    for (int v = 0; v < V; ++v) s += y[v] + w[v] + f[v] + z[3][v];
+    if (threadIdx.x == 0) { out[blockIdx.x] = s + sink[0]; cyc[blockIdx.x] = t1 - t0; }
 }
 
-int main()
+template <int WHAT>
+__global__ __launch_bounds__(64, 1) void bench_wave(const double *par, double *out, long long *cyc, int iters)
 {
+    __shared__ double2 fac_lds[kFactorLdsBytes / 16];
+    WaveBackend bk(threadIdx.x, fac_lds);
+    bk.set_problem(make_par<double>(par, 2000.0 / 128), 128);
+    body<WaveBackend, WHAT>(bk, out, cyc, iters);
+}
+template <int WHAT, int NREG>
+__global__ __launch_bounds__(128, 1) void bench_pair(const double *par, double *out, long long *cyc, int iters)
+{
+    using BK = PairBackend<2, NREG>;
+    __shared__ double2 blk_lds[BK::kBlkBytes > 0 ? BK::kBlkBytes / 16 : 1];
+    __shared__ double2 xs_lds[BK::kXchBytes / 16];
+    BK bk(threadIdx.x, blk_lds, reinterpret_cast<double *>(xs_lds));
+    bk.set_problem(make_par<double>(par, 2000.0 / 128), 128);
+    body<BK, WHAT>(bk, out, cyc, iters);
+}
+
+int main(int argc, char **argv)
+{
+    const int nblk = argc > 1 ? atoi(argv[1]) : 256;  // workgroups in flight (256: one solve per CU)
     double par[16] = {1e-13, 3e-6, 2e6, 2e6, 48, 4.4e4, 4.4e4, 0.1, 0.1, 511, 871, 10, 300, 0, 0, 1};
-    double *d_par, *d_out; long long *d_cyc;
-    hipMalloc(&d_par, sizeof(par)); hipMalloc(&d_out, 1024 * 8); hipMalloc(&d_cyc, 1024 * 8);
+    double *d_par, *d_out;
+    long long *d_cyc;
+    hipMalloc(&d_par, sizeof(par)); hipMalloc(&d_out, 4096 * 8); hipMalloc(&d_cyc, 4096 * 8);
     hipMemcpy(d_par, par, sizeof(par), hipMemcpyHostToDevice);
-    const char *names[] = {"wnorm", "rhs_std", "apply_factors", "predict(5)", "update(5)", "dense+signal", "build_factors", "change_D", "sel norms", "wave_sum"};
     const int iters = 2000;
-    std::vector<long long> c(1024);
-#define RUN(W) { hipLaunchKernelGGL(bench<W>, dim3(1024), dim3(64), 0, 0, d_par, d_out, d_cyc, iters); hipDeviceSynchronize(); \
-    hipLaunchKernelGGL(bench<W>, dim3(1024), dim3(64), 0, 0, d_par, d_out, d_cyc, iters); hipDeviceSynchronize(); \
-    hipMemcpy(c.data(), d_cyc, 1024 * 8, hipMemcpyDeviceToHost); double m = 0; for (auto x : c) m += x; \
-    printf("%-14s %8.0f cycles/call (1024 waves, one per SIMD)\n", names[W], m / 1024 / iters); }
-    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9)
+    std::vector<long long> c(4096);
+    double res[2][NWHAT];
+#define RUN(K, W, KERN, T)                                                                            \
+    {                                                                                                 \
+        for (int rep = 0; rep < 2; ++rep) {                                                           \
+            hipLaunchKernelGGL(KERN, dim3(nblk), dim3(T), 0, 0, d_par, d_out, d_cyc, iters);          \
+            hipDeviceSynchronize();                                                                   \
+        }                                                                                             \
+        hipMemcpy(c.data(), d_cyc, nblk * 8, hipMemcpyDeviceToHost);                                  \
+        double m = 0;                                                                                 \
+        for (int i = 0; i < nblk; ++i) m += c[i];                                                     \
+        res[K][W] = m / nblk / iters;                                                                 \
+    }
+#define BOTH(W) RUN(0, W, (bench_wave<W>), 64) RUN(1, W, (bench_pair<W, 3>), 128)
+    BOTH(RHS) BOTH(APPLY) BOTH(BUILD) BOTH(REDUCE2) BOTH(REDUCE4) BOTH(PUBLISH) BOTH(PREDICT) BOTH(CORRECT) BOTH(DENSE)
+    printf("%-12s %12s %12s   (cycles per call, %d workgroups)\n", "block", "wave", "pair<2,3>", nblk);
+    for (int w = 0; w < NWHAT; ++w) printf("%-12s %12.0f %12.0f\n", kNames[w], res[0][w], res[1][w]);
     return 0;
 }
