@@ -15,9 +15,18 @@
  *    caller pointer after a call returns;
  *  - every function returns an int status (MTRPL_OK = 0); nothing throws
  *    across the boundary; mtrpl_last_error() gives the message;
- *  - "host" entry points take host pointers and do the H2D/D2H themselves;
- *    "_dev" entry points take device pointers + a hipStream_t (as void*) and
- *    are asynchronous on that stream (inputs resident in HBM);
+ *  - "host" entry points take host pointers, do the H2D/D2H themselves through
+ *    device scratch the context keeps (no allocation per call once warm) and
+ *    block until the result is in the caller's buffers;
+ *  - "_dev" entry points take device pointers + a hipStream_t (as void*) and
+ *    are asynchronous on that stream (inputs resident in HBM).  Launches on
+ *    DIFFERENT streams of one context may be in flight together: every piece
+ *    of device memory a launch needs beyond the caller's buffers (the
+ *    elimination-block slab of nx > 256 solves, the work space of long traces
+ *    in the likelihood kernel) is private to that launch -- handed out from a
+ *    per-context pool and only re-used once the launch has completed or by a
+ *    later launch on the same stream.  The context itself is not thread-safe:
+ *    one host thread issues the calls;
  *  - all arithmetic is IEEE fp64.
  */
 #ifndef METROTRPL_AMD_H
@@ -62,8 +71,18 @@ typedef struct mtrpl_solve_desc {
     double par[16];   /* MTRPL_P_* slots */
     double thickness; /* Grid.thickness [nm] */
     double hmax;      /* Grid.hmax: max integrator step [ns] */
-    double rtol;      /* RTOL / ATOL of the call (defaults 1e-7 / 1e-10, :18-19) */
-    double atol;
+    double rtol;      /* RTOL of the call (default 1e-7, :18).  The engine's contract is the CONVERGED
+                         solution (1e-6 gate), so RTOL acts one way: a looser value than the default
+                         is not a licence to be less accurate (internal rtol = min(0.1*RTOL, rtol_cap),
+                         then the policy factors of DESIGN.md section 3), a tighter one tightens the
+                         integration below the policy's own floor, down to the fp64 noise floor of this
+                         system (option rtol_min); a request below that is raised to it and the solve
+                         reports MTRPL_SOLVE_OK_TOL_CLAMPED.  To trade accuracy for speed raise the
+                         option rtol_cap (or force one value with rtol_force). */
+    double atol;      /* ATOL of the call (default 1e-10, :19), solver units (nm^-3 for the densities):
+                         an upper bound of the internal absolute tolerance, which is otherwise
+                         rtol_int * atol_rel * max(N0, P0).  The default changes nothing (the relative
+                         rule is far tighter); a smaller ATOL resolves a deeper tail. */
     double min_y;     /* Grid.min_y clamp (:190-192), output units */
     double ini[3];    /* fluence mode: [fluence cm^-2, alpha cm^-1, direction] (:106-113) */
     int32_t nx;       /* Grid.nx */
@@ -85,23 +104,29 @@ int mtrpl_ctx_destroy(mtrpl_ctx *ctx);
 const char *mtrpl_last_error(const mtrpl_ctx *ctx);
 const char *mtrpl_version(void);
 /* Integrator options.  Unknown key -> MTRPL_ERR_BAD_ARG.
- *   rtol_scale, rtol_cap, rtol_floor  internal rtol = clamp(rtol_scale * desc.rtol, rtol_floor, rtol_cap) ...
+ *   rtol_scale, rtol_cap              internal rtol = min(rtol_scale * desc.rtol, rtol_cap) ...
  *   trts_rtol_factor                  ... x this for TRTS solves ...
- *   amp_ref                           ... / max(1, (1 + tauP/tauN) / amp_ref)   (0 = off), never below rtol_floor
- *   atol_rel                          internal atol = rtol_int * atol_rel * max(N0, P0)
+ *   amp_ref                           ... / max(1, (1 + tauP/tauN) / amp_ref)   (0 = off) ...
+ *   rtol_floor                        ... these two policy factors never take it below rtol_floor;
+ *   rtol_min                          a caller's own RTOL does go below rtol_floor, down to rtol_min
+ *                                     (then MTRPL_SOLVE_OK_TOL_CLAMPED)
+ *   rtol_force                        > 0: internal rtol = exactly this for every solve (tolerance sweeps)
+ *   atol_rel                          internal atol = min(rtol_int * atol_rel * max(N0, P0), desc.atol)
  *   e_weight                          relative error weight of the field components (x rtol_int), TRPL solves only
  *   newton_tol, rate_max_age, rate_first_safety   simplified-Newton convergence control
- *   fresh_jac                         1: Jacobian re-evaluated at every refactorisation
  *   nq_deadband_hi                    a proposed step factor in [0.9, this) keeps the step and the factors (1.2)
- *   nq_rej_memory, nq_rej_growth      wave kernel: step growth capped at nq_rej_growth for nq_rej_memory accepted
- *                                     steps after a rejected one; nq_bias_same/_down/_up: multipliers of the step factors
+ *   nq_rej_memory, nq_rej_growth      step growth capped at nq_rej_growth for nq_rej_memory accepted steps
+ *                                     after a rejected one; nq_bias_same/_down/_up: multipliers of the step factors
  *   early_factor, early_frac          local tolerance x early_factor for steps that end before
  *                                     early_frac * (first requested sample time)
  *   honor_hmax                        1: desc.hmax is the maximum step (the reference's max_step)
  *   max_steps                         a solve that needs more stops early (status 1, tail zero-filled)
- *   kernel_variant                    std model, nx <= 128: 0 wave kernel with the Nordsieck-form BDF (default),
- *                                     3 wave kernel with the NDF difference form, 1 team kernel (test hooks)
- *   precision                         64 (product) | 32 (fp32 build of the team kernel: precision sweep only) */
+ *   kernel_variant                    std model, nx <= 128: 0 automatic (the wave kernel: one wavefront per solve);
+ *                                     2 wave kernel, 4 / 5 wave-pair kernel (two wavefronts per solve, elimination
+ *                                     blocks in registers / in LDS), 1 team kernel (the one traps and nx > 128 use);
+ *                                     pair_max_batch: with kernel_variant 0, launches of at most this many solves
+ *                                     use the wave-pair kernel (default 0)
+ *   precision                         64 (product) | 32 (fp32 instantiation of the team kernel: precision sweep only) */
 int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value);
 int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value);
 
@@ -138,6 +163,13 @@ int mtrpl_calculate_TRTS(mtrpl_ctx *ctx, int64_t rows, int32_t nx, double dx, co
                          const double *P, double mu_n, double mu_p, double n0, double p0,
                          double *out);
 
+/* forward_solver.py:267-274: calculate_RR = ks (N P - n0 p0) and calculate_photoc =
+ * q_C (mu_n (N - n0) + mu_p (P - p0)), element-wise over n values. */
+int mtrpl_calculate_RR(mtrpl_ctx *ctx, int64_t n, const double *N, const double *P, double ks,
+                       double n0, double p0, double *out);
+int mtrpl_calculate_photoc(mtrpl_ctx *ctx, int64_t n, const double *N, const double *P, double mu_n,
+                           double mu_p, double n0, double p0, double *out);
+
 /* ---- test entry: one Newton linear solve (I - c*J(y)) x = b ------------- */
 /* y, b, x: [B, 3nx+1] std layout. Exposes the kernel's E-elimination +
  * block cyclic-reduction solver for the parity tests. */
@@ -148,6 +180,10 @@ int mtrpl_newton_probe(mtrpl_ctx *ctx, int64_t B, int32_t nx, const double *par,
 /* irf_t, irf_y: [nk]; table: [nk,3] (last row zero). */
 int mtrpl_make_I_table(mtrpl_ctx *ctx, int32_t nk, const double *irf_t, const double *irf_y,
                        double *table);
+
+/* laplace.py:129-167 (I_moment) with the caller's settings: one moment I_m^n of the IRF. */
+int mtrpl_I_moment(mtrpl_ctx *ctx, int32_t nk, const double *irf_t, const double *irf_y, int32_t m,
+                   int32_t n, int32_t u_lower, int32_t u_upper, int32_t u_spacing, double *out);
 
 /* ---- a11/a12: IRF convolution (laplace.py:44-85, :170-212) -------------- */
 /* Number of convolved samples do_irf_convolution would return for a trace
@@ -185,7 +221,9 @@ int mtrpl_irf_tables_upload(mtrpl_ctx *ctx, int32_t n_tables, const int32_t *nk,
                             const double *tables /* concatenated [nk,3] */, const double *dt_irf);
 /* ll[B, nT]: -sum err_sq / (sigma^2 T + 2 u^2) per measurement and temperature;
  * -inf where the reference would return -inf.  max_nt >= every desc's nt and
- * n_exp (sizes the LDS staging; at most 1024 in this build). */
+ * n_exp: it sizes the staging of the per-sample arrays, in LDS while 48 bytes per
+ * sample fit next to the IRF tables (about 3400 samples), in a per-launch slab of
+ * device memory beyond that -- no upper limit on the trace length. */
 int mtrpl_loglik_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_like_desc *d_descs,
                            const double *d_sig, const double *d_tsteps, const double *d_exp_t,
                            const double *d_exp_y, const double *d_exp_u, const double *d_T,

@@ -20,36 +20,68 @@ __device__ inline double linspace_at(double a, double b, int num, int i)
     return (i == num - 1) ? b : a + (double)i * step;
 }
 
-// laplace.py:129-167 (I_moment, u_spacing = 1000) with scipy.integrate.simpson's
-// composite rule for an even number of equally spaced samples (basic Simpson on
-// the first N-1 samples + the Cartwright correction on the last interval).
-// One thread per (lag m, order n); laplace.py:13-41 leaves the last row zero.
-__global__ void make_I_table_kernel(const double *__restrict__ t, const double *__restrict__ y, int nk,
-                                    double *__restrict__ table)
+// scipy.integrate.simpson(f, dx=du) for NU equally spaced samples f(0..NU-1): composite Simpson for an odd
+// number of samples; for an even number the basic rule on the first NU-1 samples plus the Cartwright
+// correction on the last interval (SciPy >= 1.11).
+template <class F>
+__device__ inline double simpson_uniform(F val, int NU, double du)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 3 * nk) return;
-    const int m = idx / 3, n = idx % 3;
-    if (m >= nk - 1) { table[idx] = 0.0; return; }
-    constexpr int NU = 1000;
-    const double dt = t[1] - t[0];
-    const double du = linspace_at(0.0, 1.0, NU, 1) - linspace_at(0.0, 1.0, NU, 0);
-    const double ya = y[m + 1], yb = y[m];
-    auto val = [&](int i) {
-        const double u = linspace_at(0.0, 1.0, NU, i);
-        const double yi = linspace_at(ya, yb, NU, i);
-        const double w = (n == 0) ? 1.0 : ((n == 1) ? (u - 0.5) : (u - 0.5) * (u - 0.5));
-        return w * yi;
-    };
     double result = 0.0;
+    if (NU % 2 == 1) {
+        for (int i = 0; i < NU - 2; i += 2) result += val(i) + 4.0 * val(i + 1) + val(i + 2);
+        return result * (du / 3.0);
+    }
+    if (NU == 2) return 0.5 * du * (val(0) + val(1));
     for (int i = 0; i < NU - 3; i += 2) result += val(i) + 4.0 * val(i + 1) + val(i + 2);
     result *= du / 3.0;
     const double h0 = du, h1 = du;
     const double alpha = (2 * h1 * h1 + 3 * h0 * h1) / (6 * (h1 + h0));
     const double beta = (h1 * h1 + 3.0 * h0 * h1) / (6 * h0);
     const double eta = (h1 * h1 * h1) / (6 * h0 * (h0 + h1));
-    result += alpha * val(NU - 1) + beta * val(NU - 2) - eta * val(NU - 3);
-    table[idx] = dt * result;
+    return result + alpha * val(NU - 1) + beta * val(NU - 2) - eta * val(NU - 3);
+}
+
+// laplace.py:129-167 (I_moment): dt * simpson((u - 1/2)^n * linspace(y[m+1-u_lower], y[m+1-u_upper], NU), dx = du),
+// u = linspace(u_lower, u_upper, NU).
+__device__ inline double irf_moment(const double *__restrict__ t, const double *__restrict__ y, int m, int n,
+                                    int u_lower, int u_upper, int NU)
+{
+    const double dt = t[1] - t[0];
+    const double du = linspace_at((double)u_lower, (double)u_upper, NU, 1) - linspace_at((double)u_lower, (double)u_upper, NU, 0);
+    const double ya = y[m + 1 - u_lower], yb = y[m + 1 - u_upper];
+    auto val = [&](int i) {
+        const double u = linspace_at((double)u_lower, (double)u_upper, NU, i);
+        const double yi = linspace_at(ya, yb, NU, i);
+        double w = 1.0;
+        for (int k = 0; k < n; ++k) w *= (u - 0.5);
+        return w * yi;
+    };
+    return dt * simpson_uniform(val, NU, du);
+}
+
+// laplace.py:13-41 (make_I_tables): one thread per (lag m, order n in 0..2), u_spacing = 1000; the last
+// row stays zero.
+__global__ void make_I_table_kernel(const double *__restrict__ t, const double *__restrict__ y, int nk,
+                                    double *__restrict__ table)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 3 * nk) return;
+    const int m = idx / 3, n = idx % 3;
+    table[idx] = (m >= nk - 1) ? 0.0 : irf_moment(t, y, m, n, 0, 1, 1000);
+}
+// one moment with the caller's settings (laplace.I_moment)
+__global__ void I_moment_kernel(const double *__restrict__ t, const double *__restrict__ y, int m, int n, int u_lower,
+                                int u_upper, int NU, double *__restrict__ out)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = irf_moment(t, y, m, n, u_lower, u_upper, NU);
+}
+// forward_solver.py:267-274: calculate_RR / calculate_photoc, element-wise
+__global__ void density_kernel(const double *__restrict__ N, const double *__restrict__ P, int64_t n, int meas, double ks,
+                               double mun, double mup, double n0, double p0, double *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (meas == MTRPL_MEAS_TRPL) ? ks * (N[i] * P[i] - n0 * p0) : kQC * (mun * (N[i] - n0) + mup * (P[i] - p0));
 }
 
 // 1-D linear interpolation exactly as scipy.interpolate.griddata does it for 1-D

@@ -667,6 +667,40 @@ int mtrpl_calculate_TRTS(mtrpl_ctx *ctx, int64_t rows, int32_t nx, double dx, co
     return integral_host(ctx, rows, nx, dx, N, P, MTRPL_MEAS_TRTS, 0.0, mu_n, mu_p, n0, p0, out);
 }
 
+static int density_host(mtrpl_ctx *ctx, int64_t n, const double *N, const double *P, int meas, double ks, double mun,
+                        double mup, double n0, double p0, double *out)
+{
+    if (!ctx) return MTRPL_ERR_BAD_ARG;
+    if (n <= 0) return MTRPL_OK;
+    if (!N || !P || !out) return bad(ctx, MTRPL_ERR_BAD_ARG, "bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf dn(ctx, 0), dpp(ctx, 1), dout(ctx, 2);
+    HIP_TRY(ctx, dn.alloc(sizeof(double) * (size_t)n));
+    HIP_TRY(ctx, dpp.alloc(sizeof(double) * (size_t)n));
+    HIP_TRY(ctx, dout.alloc(sizeof(double) * (size_t)n));
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(dn.p, N, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(dpp.p, P, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(density_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dn.as<double>(), dpp.as<double>(),
+                       n, meas, ks, mun, mup, n0, p0, dout.as<double>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return MTRPL_OK;
+}
+
+int mtrpl_calculate_RR(mtrpl_ctx *ctx, int64_t n, const double *N, const double *P, double ks, double n0, double p0,
+                       double *out)
+{
+    return density_host(ctx, n, N, P, MTRPL_MEAS_TRPL, ks, 0.0, 0.0, n0, p0, out);
+}
+
+int mtrpl_calculate_photoc(mtrpl_ctx *ctx, int64_t n, const double *N, const double *P, double mu_n, double mu_p,
+                           double n0, double p0, double *out)
+{
+    return density_host(ctx, n, N, P, MTRPL_MEAS_TRTS, 0.0, mu_n, mu_p, n0, p0, out);
+}
+
 #include "irf_capi.inc"
 
 }  // extern "C"

@@ -55,6 +55,36 @@ def calculate_TRTS(dx, N, P, mu_n, mu_p, n0, p0):
     return _integral("TRTS", dx, N, P, mu_n, mu_p, n0, p0)
 
 
+def _density(which, N, P, *a):
+    N = np.asarray(N, dtype=np.float64)
+    P = np.asarray(P, dtype=np.float64)
+    N, P = np.broadcast_arrays(N, P)
+    ctx = L.default_context()
+    Nf, Pf = L.f64(N.reshape(-1)), L.f64(P.reshape(-1))
+    out = np.empty(Nf.shape[0])
+    fn = L.lib().mtrpl_calculate_RR if which == "RR" else L.lib().mtrpl_calculate_photoc
+    ctx.check(fn(ctx.handle, Nf.shape[0], L.dptr(Nf), L.dptr(Pf), *a, L.dptr(out)))
+    return out.reshape(N.shape) if N.ndim else out[0]
+
+
+def calculate_RR(N, P, ks, n0, p0):
+    """forward_solver.py:267-269"""
+    return _density("RR", N, P, ks, n0, p0)
+
+
+def calculate_photoc(N, P, mu_n, mu_p, n0, p0):
+    """forward_solver.py:272-274"""
+    return _density("photoc", N, P, mu_n, mu_p, n0, p0)
+
+
+def integrate_2D(dx, y):
+    """forward_solver.py:250-255: integrate_1D of every row."""
+    y = np.asarray(y, dtype=np.float64)
+    if y.ndim != 2:
+        raise ValueError(f"Invalid number of dims (got {y.ndim} dims) in Solution")
+    return calculate_PL(dx, y, np.ones_like(y), 1.0, 0.0, 0.0)
+
+
 def integrate_1D(dx, y):
     """forward_solver.py:258-264 == dx * sum(y); evaluated by the PL kernel with N=y, P=1, ks=1."""
     y = np.asarray(y, dtype=np.float64)
@@ -66,6 +96,11 @@ def dydt_numba(t, y, L_, dx, N0, P0, mu_n, mu_p, r_rad, CN, CP, sr0, srL, tauN, 
     par = np.array([[N0, P0, mu_n, mu_p, r_rad, CN, CP, sr0, srL, tauN, tauP, q_C / (Lambda * eps0), Tm,
                      0, 0, 1.0]])
     return batch.rhs_batch(par, [dx], np.asarray(y, dtype=np.float64)[None, :], L_)[0]
+
+
+def dydt(t, y, L_, dx, N0, P0, mu_n, mu_p, r_rad, CN, CP, sr0, srL, tauN, tauP, Lambda, Tm):
+    """forward_solver.py:277-329: the reference's numpy twin of dydt_numba -- the same right-hand side."""
+    return dydt_numba(t, y, L_, dx, N0, P0, mu_n, mu_p, r_rad, CN, CP, sr0, srL, tauN, tauP, Lambda, Tm)
 
 
 def solve(iniPar, g, state, indexes, meas="TRPL", units=None, solver=("solveivp",), model="std",

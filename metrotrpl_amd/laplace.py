@@ -24,12 +24,13 @@ def make_I_tables(irfs):
 
 
 def I_moment(t, y, m, n, u_lower=0, u_upper=1, u_spacing=100):
-    """laplace.py:129-167 -- the device kernel implements the (0, 1, 1000) case
-    make_I_tables uses; other settings are not part of the hot path."""
-    if (u_lower, u_upper, u_spacing) != (0, 1, 1000):
-        raise NotImplementedError("only u_lower=0, u_upper=1, u_spacing=1000 is built")
-    tab = make_I_tables({0: np.vstack((t, y)).T})[0][0]
-    return tab[m, n]
+    """laplace.py:129-167: moment integral I_m^n of an IRF y(t), any u_spacing."""
+    ctx = L.default_context()
+    t, y = L.f64(t), L.f64(y)
+    out = C.c_double(0.0)
+    ctx.check(L.lib().mtrpl_I_moment(ctx.handle, len(y), L.dptr(t), L.dptr(y), int(m), int(n), int(u_lower),
+                                     int(u_upper), int(u_spacing), C.byref(out)))
+    return out.value
 
 
 def convolve(resampled_y, I_table):

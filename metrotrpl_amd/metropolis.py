@@ -83,21 +83,20 @@ class Walk:
         self.swap_attempts = np.zeros(self.n, dtype=int)
         self.swap_accept = np.zeros(self.n, dtype=int)
 
-    # -- random_state of a checkpoint: one generator state (serial) or one per chain (mpi)
+    # -- random_state of a checkpoint: ONE bit-generator state dict in both modes, as the reference
+    # stores it (`MS_list.random_state = RNG.bit_generator.state` on rank 0, metropolis.py:362,:446) and
+    # loads it (`RNG.bit_generator.state = RNG_state` after a bcast to every rank, :410-411).  In "mpi"
+    # mode that is chain 0's generator; a RESUMED walk therefore restarts every chain from chain 0's
+    # stream position -- the per-chain streams that had drifted apart are re-synchronised, exactly what
+    # a resumed reference run does -- so a pickle written here resumes in the reference and vice versa.
     def random_state(self):
-        if self.mode == "serial":
-            return self.rngs[0].bit_generator.state
-        return [r.bit_generator.state for r in self.rngs]
+        return self.rngs[0].bit_generator.state
 
     def set_random_state(self, state):
-        if self.mode == "serial":
-            self.rngs[0].bit_generator.state = state
-        elif isinstance(state, list):
-            for r, s in zip(self.rngs, state):
-                r.bit_generator.state = s
-        else:
-            for r in self.rngs:
-                r.bit_generator.state = state
+        if isinstance(state, list):  # checkpoints of metrotrpl_amd 0.1: one state per chain
+            state = state[0]
+        for r in self.rngs:
+            r.bit_generator.state = state
 
     def evaluate_current(self, states_k):
         self.table = self.gather(np.ascontiguousarray(states_k))
@@ -272,6 +271,14 @@ def metro(sim_info, iniPar, e_data, MCMC_fields, param_info, verbose=False, expo
         walk.run(states, logll, accept, starting_iter, ending_iter, need_initial_state=need_initial_state)
         if ending_iter == num_iters:
             break
+        if rng_mode == "mpi":
+            # main_metro_loop counts per segment and metro() adds every segment's counts before it
+            # saves (metropolis.py:431-437); the serial loop's counts are only added after the last
+            # segment (:464-466)
+            MS_list.H.swap_attempts = MS_list.H.swap_attempts + walk.swap_attempts
+            MS_list.H.swap_accept = MS_list.H.swap_accept + walk.swap_accept
+            walk.swap_attempts[:] = 0
+            walk.swap_accept[:] = 0
         MS_list.latest_iter = ending_iter
         MS_list.H.pack(states, logll, accept)
         MS_list.random_state = walk.random_state()

@@ -11,6 +11,8 @@ import numpy as np
 
 from .sim_utils import MAX_PROPOSALS
 
+MU_SEED = 235817049752375781  # the walk's seed (metropolis.py:296) + 1
+
 
 def approve_move(new_state, shared_fields):
     """Names of the failed checks (empty list = approved), trial_move_generation.py:4-49.
@@ -47,10 +49,15 @@ def make_trial_move(current_state, trial_move, shared_fields, RNG, logger=None):
     for tries in range(1, max_tries + 1):
         new = cur + trial_move * (2 * RNG.random(cur.shape) - 1)
         if mu_constraint is not None:
-            # ambipolar-mobility constraint, drawn from numpy's GLOBAL generator as the
-            # reference does (trial_move_generation.py:79-85)
+            # ambipolar-mobility constraint (trial_move_generation.py:79-85).  The reference draws it from
+            # numpy's GLOBAL, unseeded generator; here every rank replays every chain's proposals and
+            # must see the same value, so it comes from a generator of its own with a fixed seed (kept in
+            # shared_fields, hence in the checkpoints): RNG's stream stays the reference's.
             ambi, ambi_std = mu_constraint[0], mu_constraint[1]
-            mu_a = np.random.uniform(ambi - ambi_std, ambi + ambi_std)
+            mu_rng = shared_fields.get("_mu_rng")
+            if mu_rng is None:
+                mu_rng = shared_fields["_mu_rng"] = np.random.default_rng(MU_SEED)
+            mu_a = mu_rng.uniform(ambi - ambi_std, ambi + ambi_std)
             ix = shared_fields["_param_indexes"]
             new[ix["mu_p"]] = np.log10((2 / mu_a - 1 / 10 ** new[ix["mu_n"]]) ** -1)
         failed = approve_move(new, shared_fields)

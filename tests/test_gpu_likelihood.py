@@ -150,3 +150,31 @@ def test_loglik_irf_on_unaligned_time_grids(kind):
     _, ref = O.eval_trial_move(state, dict(uniq, _T=1.0), tight, temperatures=TEMPS)
     assert np.all(np.isfinite(ref))
     np.testing.assert_allclose(table, ref, rtol=1e-6)
+
+
+@pytest.mark.parametrize("n,t_end", [(2501, 250.0), (4001, 200.0), (6001, 150.0)])
+def test_loglik_long_traces(n, t_end):
+    """Real TRPL files run to thousands of samples and the reference has no limit
+    (trial_move_evaluation.py:96-158).  2501 samples: per-sample arrays in LDS beyond the 64 KB default
+    (one block per CU); 4001 and 6001: per-block work space in device memory.  With IRF convolution, against
+    the oracle's definition-order sums; the no-IRF case of the same traces as well."""
+    from oracle import oracle as O
+    ev, state, uniq, shared = _setup("irf")
+    t = np.linspace(0, t_end, n)
+    shared = dict(shared, _times=[t, t], _vals=[23 - np.linspace(0, 1, n), 24 - np.linspace(0, 2, n)],
+                  _uncs=[np.full(n, 0.02), np.full(n, 0.02)])
+    for irf_on in (True, False):
+        sh = dict(shared) if irf_on else dict(shared, irf_convolution=None)
+        eng = _engine(state, uniq, sh)
+        table = eng.eval(np.asarray(state)[None, :], TEMPS)[0]
+        tight = dict(sh, rtol=1e-10, atol=1e-14)
+        _, ref = O.eval_trial_move(state, dict(uniq, _T=1.0), tight, temperatures=TEMPS)
+        assert np.all(np.isfinite(ref))
+        np.testing.assert_allclose(table, ref, rtol=1e-6)
+    # several chains at once through the strided-block variant: same values as one at a time
+    eng = _engine(state, uniq, shared)
+    states = np.stack([np.asarray(state, dtype=float)] * 3)
+    states[1, shared["_param_indexes"]["ks"]] *= 2.0
+    all3 = eng.eval(states, TEMPS)
+    for c in range(3):
+        np.testing.assert_array_equal(eng.eval(states[c:c + 1], TEMPS)[0], all3[c])

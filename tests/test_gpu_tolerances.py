@@ -1,0 +1,63 @@
+"""What the caller's RTOL / ATOL do (include/metrotrpl_amd.h, mtrpl_solve_desc.rtol / .atol; reference
+semantics: forward_solver.py:163-165 hands both to LSODA).  The engine's contract is the converged trace,
+so a loose RTOL changes nothing, a tight one tightens the integration below the policy's own floor, a
+request below the noise floor is raised to it and reported, and ATOL bounds the absolute term from above."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _solve(z, sel, rtol=None, atol=None):
+    from metrotrpl_amd import batch
+    idx = {n: i for i, n in enumerate(str(z["names"]).split(","))}
+    return batch.solve_batch(z["states"][sel], idx, z["units"], z["iniPar"][sel], z["thickness"][sel], 128, z["tSteps"],
+                             RTOL=rtol, ATOL=atol, return_stats=True)
+
+
+def _err(sig, ref, lo_dec, hi_dec):
+    with np.errstate(all="ignore"):
+        dec = np.floor(np.log10(ref[:, :1] / ref))
+        rel = np.abs(sig - ref) / ref
+    m = (dec >= lo_dec) & (dec < hi_dec)
+    return float(rel[m].max())
+
+
+def test_tight_rtol_is_honoured_loose_rtol_is_not_a_licence():
+    z = np.load(os.path.join(G, "tail_decades.npz"))
+    sel = np.arange(0, 48)
+    ref = z["sig"][sel]
+    base, st0, stats0 = _solve(z, sel)                 # defaults 1e-7 / 1e-10
+    loose, st1, stats1 = _solve(z, sel, rtol=1e-3)     # looser than the default: same integration
+    tight, st2, stats2 = _solve(z, sel, rtol=1e-9)     # 0.1 * 1e-9 = 1e-10 < the policy floor of 3e-10: honoured
+    assert np.all(st0 == 0) and np.all(st1 == 0) and np.all(st2 == 0)
+    np.testing.assert_array_equal(loose, base)
+    np.testing.assert_array_equal(stats1[:, 0], stats0[:, 0])
+    e_base, e_tight = _err(base, ref, 0, 4), _err(tight, ref, 0, 4)
+    print(f"first four decades: default {e_base:.2e} ({stats0[:, 0].mean():.0f} steps), RTOL=1e-9 {e_tight:.2e} "
+          f"({stats2[:, 0].mean():.0f} steps)")
+    assert e_base <= 1e-6
+    assert e_tight < 0.5 * e_base and stats2[:, 0].mean() > 1.15 * stats0[:, 0].mean()
+    # below the noise floor of this system: raised to it, and the solve says so
+    floor_, st3, stats3 = _solve(z, sel[:8], rtol=1e-13)
+    assert np.all(st3 == 2), st3  # MTRPL_SOLVE_OK_TOL_CLAMPED
+    assert np.all(np.isfinite(floor_)) and _err(floor_, ref[:8], 0, 4) <= 1e-6
+
+
+def test_atol_bounds_the_absolute_term():
+    z = np.load(os.path.join(G, "tail_decades.npz"))
+    sel = np.arange(256, 256 + 48)  # the config-3 geometry: thin films decay through many decades
+    ref = z["sig"][sel]
+    base, st0, stats0 = _solve(z, sel)
+    same, st1, stats1 = _solve(z, sel, atol=1e-3)      # looser than the relative rule: nothing changes
+    deep, st2, stats2 = _solve(z, sel, atol=1e-24)     # a smaller ATOL resolves a deeper tail
+    assert np.all(st0 == 0) and np.all(st2 == 0)
+    np.testing.assert_array_equal(same, base)
+    assert stats2[:, 0].mean() > 1.02 * stats0[:, 0].mean(), (stats2[:, 0].mean(), stats0[:, 0].mean())
+    e_base, e_deep = _err(base, ref, 6, 9), _err(deep, ref, 6, 9)
+    print(f"decades 6-8: default {e_base:.2e} ({stats0[:, 0].mean():.0f} steps), ATOL=1e-24 {e_deep:.2e} "
+          f"({stats2[:, 0].mean():.0f} steps)")
+    assert e_deep < 0.2 * e_base

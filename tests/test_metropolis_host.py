@@ -195,3 +195,85 @@ def test_load_a_pickle_written_by_the_reference():
     # and it can be continued: extend the record and re-checkpoint under the reference's class path
     E.H.extend(30)
     assert E.H.states.shape == (3, 14, 30)
+
+
+def _mpi_case(tmp_path):
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mcmc.npz"))
+    import json
+    cfg = json.loads(str(z["pt__config"]))
+
+    def fields(num_iters, ckpt_freq, load, **extra):
+        pi, si, mf = copy.deepcopy(cfg["param_info"]), copy.deepcopy(cfg["sim_info"]), copy.deepcopy(cfg["MCMC_fields"])
+        pi["prior_dist"] = {k: tuple(v) for k, v in pi["prior_dist"].items()}
+        mf.update(num_iters=num_iters, checkpoint_freq=ckpt_freq, load_checkpoint=load, output_path=str(tmp_path),
+                  irf_convolution=None, **extra)
+        return si, pi, mf
+    times = z["pt__times"]
+    e_data = ([times, times], [v for v in z["pt__vals"]], [u for u in z["pt__uncs"]])
+    T = np.asarray(cfg["MCMC_fields"]["parallel_tempering"], dtype=float)
+
+    def gather(states):  # cheap deterministic stand-in for the simulator
+        base = -np.sum((np.log10(states[:, [9, 10]]) - np.log10([300.0, 600.0])) ** 2, axis=1) * 40
+        return base[:, None] / T[None, :]
+    return z, fields, e_data, gather
+
+
+def test_mpi_mode_checkpoint_is_the_reference_format_and_resumes(tmp_path):
+    """rng_mode="mpi" (the default): the pickle holds ONE bit-generator state dict, the one the reference
+    assigns with `RNG.bit_generator.state = RNG_state` on every rank (metropolis.py:410-411); every segment's
+    swap counts are in the checkpoint that closes it (:431-437); resuming re-synchronises every chain's
+    generator to that state, as a resumed reference run does, and is deterministic."""
+    z, fields, e_data, gather = _mpi_case(tmp_path)
+    si, pi, mf = fields(12, 6, None)
+    M.metro(si, z["pt__iniPar"].copy(), e_data, mf, pi, export_path="a.pik", gather=gather, logger_name="a")
+    # the file at this point is the FINAL export; re-run to 6 only to look at an intermediate one
+    si, pi, mf = fields(6, 6, None)
+    half = M.metro(si, z["pt__iniPar"].copy(), e_data, mf, pi, export_path="half.pik", gather=gather, logger_name="h")
+    ck = S.load_pickle(str(tmp_path / "half.pik"))
+    assert isinstance(ck.random_state, dict) and ck.random_state["bit_generator"] == "PCG64"
+    rng = np.random.default_rng(0)
+    rng.bit_generator.state = ck.random_state           # what the reference does with it
+    assert ck.latest_iter == 6
+    assert ck.H.swap_attempts.sum() > 0                  # temper_freq = 2: three swap steps in 6 iterations
+    # intermediate checkpoints carry the counts of the segments before them
+    si, pi, mf = fields(12, 4, None)
+    M.metro(si, z["pt__iniPar"].copy(), e_data, mf, pi, export_path="seg.pik", gather=gather, logger_name="s")
+    # (the run above ends with the final export; its swap totals must equal the uninterrupted run's)
+    full = S.load_pickle(str(tmp_path / "a.pik"))
+    seg = S.load_pickle(str(tmp_path / "seg.pik"))
+    np.testing.assert_array_equal(seg.H.swap_attempts, full.H.swap_attempts)
+    np.testing.assert_array_equal(seg.H.states, full.H.states)
+    # resume twice from the same file: identical walks, all chains restarted from chain 0's stream
+    outs = []
+    for tag in ("r1", "r2"):
+        si, pi, mf = fields(12, 6, "half.pik")
+        outs.append(M.metro(si, z["pt__iniPar"].copy(), e_data, mf, pi, export_path=tag + ".pik", gather=gather,
+                            logger_name=tag))
+    np.testing.assert_array_equal(outs[0].H.states, outs[1].H.states)
+    np.testing.assert_array_equal(outs[0].H.states[:, :, :6], half.H.states[:, :, :6])
+    assert outs[0].H.accept[:, 6:].sum() > 0
+    w = M.Walk(outs[0].ensemble_fields, outs[0].unique_fields, np.random.default_rng(1), gather, rng_mode="mpi")
+    w.set_random_state(ck.random_state)
+    assert all(r.bit_generator.state == ck.random_state for r in w.rngs)
+    # a checkpoint of the previous package version (one state per chain) still loads
+    w.set_random_state([ck.random_state] * 3)
+    assert w.random_state() == ck.random_state
+
+
+def test_mu_constraint_draws_are_replayable(tmp_path):
+    """do_mu_constraint: the reference draws the ambipolar mobility from numpy's global generator
+    (trial_move_generation.py:79-85); a sharded walk replays every chain's proposals on every rank, so the
+    draw has to come from a seeded stream: two runs give the same walk, whatever the global state is."""
+    z, fields, e_data, gather = _mpi_case(tmp_path)
+    outs = []
+    for k, tag in enumerate(("m1", "m2")):
+        np.random.seed(1234 + k)  # must not matter
+        si, pi, mf = fields(8, 8, None, do_mu_constraint=[20.0, 3.0])
+        outs.append(M.metro(si, z["pt__iniPar"].copy(), e_data, mf, pi, export_path=tag + ".pik", gather=gather,
+                            logger_name=tag))
+    np.testing.assert_array_equal(outs[0].H.states, outs[1].H.states)
+    ix = outs[0].ensemble_fields["_param_indexes"]
+    mu_n, mu_p = outs[0].H.states[:, ix["mu_n"], 1:], outs[0].H.states[:, ix["mu_p"], 1:]
+    ambi = 2.0 / (1.0 / mu_n + 1.0 / mu_p)
+    moved = outs[0].H.accept[:, 1:] == 1
+    assert moved.any() and np.all(np.abs(ambi[moved] - 20.0) <= 3.0 + 1e-9)
