@@ -80,9 +80,10 @@ typedef struct mtrpl_solve_desc {
                          reports MTRPL_SOLVE_OK_TOL_CLAMPED.  To trade accuracy for speed raise the
                          option rtol_cap (or force one value with rtol_force). */
     double atol;      /* ATOL of the call (default 1e-10, :19), solver units (nm^-3 for the densities):
-                         an upper bound of the internal absolute tolerance, which is otherwise
-                         rtol_int * atol_rel * max(N0, P0).  The default changes nothing (the relative
-                         rule is far tighter); a smaller ATOL resolves a deeper tail. */
+                         an upper bound of the absolute tolerance of the densities, which is otherwise
+                         rtol_int * atol_rel_np * max(N0, P0) (about 3e-21 nm^-3).  The default changes
+                         nothing (the rule is far tighter); a smaller ATOL resolves a still deeper tail.
+                         The field keeps its own absolute floor (option atol_rel). */
     double min_y;     /* Grid.min_y clamp (:190-192), output units */
     double ini[3];    /* fluence mode: [fluence cm^-2, alpha cm^-1, direction] (:106-113) */
     int32_t nx;       /* Grid.nx */
@@ -111,7 +112,9 @@ const char *mtrpl_version(void);
  *   rtol_min                          a caller's own RTOL does go below rtol_floor, down to rtol_min
  *                                     (then MTRPL_SOLVE_OK_TOL_CLAMPED)
  *   rtol_force                        > 0: internal rtol = exactly this for every solve (tolerance sweeps)
- *   atol_rel                          internal atol = min(rtol_int * atol_rel * max(N0, P0), desc.atol)
+ *   atol_rel                          absolute tolerance of the field components = rtol_int * atol_rel * max(N0, P0)
+ *   atol_rel_np                       ... of the densities = min(rtol_int * atol_rel_np * max(N0, P0), desc.atol):
+ *                                     1e-8 resolves a trace over 8 decades of decay (1e-4: the first 4, 6 % fewer steps)
  *   e_weight                          relative error weight of the field components (x rtol_int), TRPL solves only
  *   newton_tol, rate_max_age, rate_first_safety   simplified-Newton convergence control
  *   nq_deadband_hi                    a proposed step factor in [0.9, this) keeps the step and the factors (1.2)

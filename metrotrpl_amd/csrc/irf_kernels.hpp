@@ -248,7 +248,8 @@ __global__ void conv_time_kernel(int64_t n_conv, int64_t n_r, double half_dt, do
 // sample (and the snapped last one) are evaluated directly from the definition.
 constexpr int kLikeBlock = 768;   // 8 waves per trace: two blocks per CU keep 4 waves per SIMD in flight
 constexpr int kLikeWaves = kLikeBlock / 64;
-constexpr int kLikeLdsBytes = 160 * 1024;  // per-CU LDS: above this the per-sample arrays move to global memory
+constexpr int kLikeLdsBytes = 159 * 1024;  // dynamic LDS a block may ask for (160 KB per CU minus the kernel's static
+                                           // reduction scratch): above this the per-sample arrays move to global memory
 constexpr int kLikeGworkBlocks = 1024;     // blocks of the global-work-space variant (4 per CU)
 
 struct ConvCtx {

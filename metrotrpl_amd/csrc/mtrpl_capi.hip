@@ -33,7 +33,7 @@ struct Slab {
 struct mtrpl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    SolveTuning tune{0.1, 3e-9, 3e-10, 1e-11, 0.0, 1e-4, 2000000, 0.03, 8, 4.0, 3.0, 1, 0.5, 16.0, 1.2, 80, 1.2, 1.0, 1.0, 1.0, 10.0, 0.5};
+    SolveTuning tune{0.1, 3e-9, 3e-10, 3e-11, 0.0, 1e-4, 1e-8, 2000000, 0.03, 8, 4.0, 3.0, 1, 0.5, 16.0, 1.2, 80, 1.2, 1.0, 1.0, 1.0, 10.0, 0.5};
     std::string err;
     // IRF tables resident on the device (mtrpl_irf_tables_upload)
     double *d_irf_tab = nullptr;
@@ -399,7 +399,7 @@ const OptD kOptD[] = {
     {"rtol_scale", &SolveTuning::rtol_scale}, {"rtol_cap", &SolveTuning::rtol_cap},
     {"rtol_floor", &SolveTuning::rtol_floor}, {"rtol_min", &SolveTuning::rtol_min},
     {"rtol_force", &SolveTuning::rtol_force},
-    {"atol_rel", &SolveTuning::atol_rel}, {"newton_tol", &SolveTuning::newton_tol},
+    {"atol_rel", &SolveTuning::atol_rel}, {"atol_rel_np", &SolveTuning::atol_rel_np}, {"newton_tol", &SolveTuning::newton_tol},
     {"rate_first_safety", &SolveTuning::rate_first_safety}, {"e_weight", &SolveTuning::e_weight},
     {"trts_rtol_factor", &SolveTuning::trts_rtol_factor}, {"amp_ref", &SolveTuning::amp_ref},
     {"nq_deadband_hi", &SolveTuning::nq_deadband_hi}, {"nq_rej_growth", &SolveTuning::nq_rej_growth},

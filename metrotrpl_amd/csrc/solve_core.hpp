@@ -65,7 +65,8 @@ struct SolveTuning {
     double rtol_floor;  // the policy factors (TRTS, tauP/tauN) never tighten below this ...
     double rtol_min;    // ... but a caller's own RTOL does, down to this noise floor (then status 2)
     double rtol_force;  // > 0: internal rtol = exactly this for every solve (tolerance sweeps); 0: the policy
-    double atol_rel;    // internal atol = min(rtol_int * atol_rel * max(N0, P0 over the film), desc.atol)
+    double atol_rel;    // absolute tolerance of the FIELD components = rtol_int * atol_rel * max(N0, P0 over the film)
+    double atol_rel_np; // ... and of the densities = min(rtol_int * atol_rel_np * max(N0, P0), desc.atol)
     int max_steps;
     double newton_tol;  // <= 0: SciPy's rule max(10 eps/rtol, min(0.03, sqrt(rtol))); else this value
     int rate_max_age;   // consecutive 1-iteration Newton solves allowed on a carried-over rate (0: always >= 2)
@@ -254,7 +255,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
     // (rtol_cap); a tight one tightens it, below the policy floor too, down to the fp64 noise floor
     // rtol_min -- a request below that is raised to it and reported as MTRPL_SOLVE_OK_TOL_CLAMPED.
     bool tol_clamped = false;
-    real rtol, atol;
+    real rtol, atol, atol_E;
     {
         const double req = tune.rtol_scale * ds.rtol;
         const double base = fmin(req, tune.rtol_cap);
@@ -275,15 +276,20 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         }
         if (tune.rtol_force > 0.0) { r_ = tune.rtol_force; tol_clamped = false; }
         rtol = (real)r_;
-        // desc.atol (solver units, nm^-3) bounds the absolute term from above: the default 1e-10 is far
-        // looser than the relative rule and changes nothing; a smaller ATOL tightens the deep tail.
-        atol = (real)fmin(r_ * tune.atol_rel * (double)dNmax, ds.atol);
+        // Absolute terms.  The densities are resolved RELATIVELY deep into the tail of a trace (a
+        // low-injection decay takes the excess density many decades down; the signal follows it), so their
+        // absolute term is tiny; desc.atol (solver units, nm^-3) bounds it from above -- the default 1e-10
+        // never does.  The field passes through zero and keeps an absolute floor in the scale of the
+        // problem (a tiny one makes every BDF code crawl there, LSODA included).
+        atol = (real)fmin(r_ * tune.atol_rel_np * (double)dNmax, ds.atol);
+        atol_E = (real)(r_ * tune.atol_rel * (double)dNmax);
     }
     // the field is a fast slaved variable (dielectric relaxation): its local error is damped, not
     // accumulated, so it gets a looser relative weight than the densities (DESIGN.md "error control")
     // (TRPL only: the photoconductivity weighs dP directly, and its p99 census error doubles with a looser field)
     const real rtol_E = rtol * ((meas == MTRPL_MEAS_TRPL) ? (real)tune.e_weight : (real)1);
     auto rtol_of = [&](int v) { return (v >= 2 * R && v < 3 * R) ? rtol_E : rtol; };
+    auto atol_of = [&](int v) { return (v >= 2 * R && v < 3 * R) ? atol_E : atol; };
     const real early_until = (nt > 1) ? (real)(tune.early_frac * ts[1]) : (real)0;
     const real early_inv = (real)(1.0 / fmax(tune.early_factor, 1.0));
     const real newton_tol = (tune.newton_tol > 0.0)
@@ -325,10 +331,10 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             return norm_sqrt(s3[0] * inv_S);
         };
 #pragma unroll
-        for (int v = 0; v < V; ++v) w[v] = y[v] / (atol + rtol_of(v) * fabs(y[v]));
+        for (int v = 0; v < V; ++v) w[v] = y[v] / (atol_of(v) + rtol_of(v) * fabs(y[v]));
         const real d0 = tnorm(w);
 #pragma unroll
-        for (int v = 0; v < V; ++v) w[v] = f[v] / (atol + rtol_of(v) * fabs(y[v]));
+        for (int v = 0; v < V; ++v) w[v] = f[v] / (atol_of(v) + rtol_of(v) * fabs(y[v]));
         const real d1 = tnorm(w);
         real h0 = (d0 < (real)1e-5 || d1 < (real)1e-5) ? (real)1e-6 : (real)0.01 * d0 / d1;
         real y1[V], f1[V];
@@ -338,7 +344,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         bk.rhs(y1, f1);
         n_rhs++;
 #pragma unroll
-        for (int v = 0; v < V; ++v) w[v] = (f1[v] - f[v]) / (atol + rtol_of(v) * fabs(y[v]));
+        for (int v = 0; v < V; ++v) w[v] = (f1[v] - f[v]) / (atol_of(v) + rtol_of(v) * fabs(y[v]));
         const real d2 = tnorm(w) / h0;
         const real dm = fmax(d1, d2);
         const real h1 = (dm <= (real)1e-15) ? fmax((real)1e-6, h0 * (real)1e-3) : (real)sqrt((real)0.01 / dm);
@@ -390,7 +396,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             const real c = h * el0;
             const real early_scale = (tune.early_factor > 1.0 && t + h <= early_until) ? early_inv : (real)1;
 #pragma unroll
-            for (int v = 0; v < V; ++v) isc[v] = ctl_rcp(atol + rtol_of(v) * fabs(z[0][v])) * early_scale;
+            for (int v = 0; v < V; ++v) isc[v] = ctl_rcp(atol_of(v) + rtol_of(v) * fabs(z[0][v])) * early_scale;
             MTRPL_STAMP(ph_ctl);
             // simplified Newton on acor:  (I - h l0 J) dx = h f(y) - z[1] - acor,  y = z[0] + l0 acor
             bool converged = false, fresh = false;

@@ -157,18 +157,33 @@ def test_golden_solves_tight(gold, conv):
     print("worst rel err:", worst)
 
 
-def test_golden_solves_default_reference(gold):
-    """Against the reference at ITS default tolerances the floor is the reference's
-    own error (1.9e-6 vs converged)."""
+def test_golden_solves_default_reference(gold, conv):
+    """Against the reference at ITS default tolerances (RTOL=1e-7 / ATOL=1e-10) the floor is the reference's
+    own error: its default-tolerance traces are up to 1e-3 from the converged ones inside the 4-decade
+    window (cfg2_11).  So every `__default` golden of configs 1, 2 and 3 is held to two bounds that cannot be
+    loosened by picking cases: the GPU trace is within the gate of the CONVERGED trace, and it is at least
+    as close to the reference's default output as that output is to the converged trace."""
+    n = 0
+    worst_gap = 0.0
     for key in [str(k) for k in gold["order"]]:
-        if not key.endswith("__default") or not (key.startswith("cfg1") or key.startswith("cfg3")):
+        if not key.endswith("__default") or not key.startswith(("cfg1", "cfg2", "cfg3")):
             continue
         c = _case(gold, key)
-        if c["nx"] > 128:
+        ck = key.replace("__default", "__conv")
+        if c["model"] != "std" or c["nx"] > 128 or c["min_y"] is not None or ck not in conv.files:
             continue
         sig, status, _ = _run(c)
-        err, _ = _relerr(sig, c["sig"])
-        assert err <= 1e-5, (key, err)  # measured: 3.1e-4 (cfg2_2, a fast decay) -- the reference's own default-tolerance error; our trace is within 3e-7 of the converged one
+        assert status == 0, key
+        err_conv, _ = _relerr(sig, conv[ck])
+        err_ref, _ = _relerr(sig, c["sig"])
+        ref_gap, _ = _relerr(c["sig"], conv[ck])
+        worst_gap = max(worst_gap, ref_gap)
+        print(f"{key}: gpu vs converged {err_conv:.2e}, gpu vs ref default {err_ref:.2e}, ref default vs converged {ref_gap:.2e}")
+        assert err_conv <= REL_TOL, (key, err_conv)
+        assert err_ref <= 1.05 * ref_gap + 1e-6, (key, err_ref, ref_gap)
+        n += 1
+    assert n >= 12, n
+    assert worst_gap > 1e-5  # the reference's default tolerance really is the floor here
 
 
 def test_min_y_clamp(gold):
@@ -176,7 +191,7 @@ def test_min_y_clamp(gold):
     c = _case(gold, "tm_depl__tight")
     sig, status, _ = _run(c)
     ref = c["sig"]
-    assert status == 0
+    assert status in (0, 2)  # the case asks for RTOL=1e-10: below the noise floor, raised to it (status 2)
     assert np.min(sig) >= c["min_y"]
     np.testing.assert_array_equal(sig[-10:], c["min_y"])
     first_ref = int(np.argmax(ref == c["min_y"]))

@@ -52,12 +52,14 @@ def test_atol_bounds_the_absolute_term():
     sel = np.arange(256, 256 + 48)  # the config-3 geometry: thin films decay through many decades
     ref = z["sig"][sel]
     base, st0, stats0 = _solve(z, sel)
-    same, st1, stats1 = _solve(z, sel, atol=1e-3)      # looser than the relative rule: nothing changes
-    deep, st2, stats2 = _solve(z, sel, atol=1e-24)     # a smaller ATOL resolves a deeper tail
+    same, st1, stats1 = _solve(z, sel, atol=1e-3)      # looser than the rule (about 3e-21 nm^-3): nothing changes
+    deep, st2, stats2 = _solve(z, sel, atol=1e-25)     # a smaller ATOL resolves a still deeper tail
     assert np.all(st0 == 0) and np.all(st2 == 0)
     np.testing.assert_array_equal(same, base)
-    assert stats2[:, 0].mean() > 1.02 * stats0[:, 0].mean(), (stats2[:, 0].mean(), stats0[:, 0].mean())
-    e_base, e_deep = _err(base, ref, 6, 9), _err(deep, ref, 6, 9)
-    print(f"decades 6-8: default {e_base:.2e} ({stats0[:, 0].mean():.0f} steps), ATOL=1e-24 {e_deep:.2e} "
+    e_base, e_deep = _err(base, ref, 9, 12), _err(deep, ref, 9, 12)
+    print(f"decades 9-11: default {e_base:.2e} ({stats0[:, 0].mean():.0f} steps), ATOL=1e-25 {e_deep:.2e} "
           f"({stats2[:, 0].mean():.0f} steps)")
-    assert e_deep < 0.2 * e_base
+    assert stats2[:, 0].mean() > 1.005 * stats0[:, 0].mean(), (stats2[:, 0].mean(), stats0[:, 0].mean())
+    assert e_deep < 0.7 * e_base
+    # the field keeps its own absolute floor: a tiny ATOL does not send the integrator crawling
+    assert stats2[:, 0].max() < 3 * stats0[:, 0].max()

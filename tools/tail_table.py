@@ -17,7 +17,7 @@ sys.path.insert(0, REPO)
 
 def per_decade(sig, ref, max_dec=12):
     with np.errstate(divide="ignore", invalid="ignore"):
-        dec = np.floor(np.log10(np.abs(ref[:, :1]) / np.maximum(np.abs(ref), 1e-300))).astype(int)
+        dec = np.floor(np.log10(np.abs(ref[:, :1])) - np.log10(np.maximum(np.abs(ref), 1e-300))).astype(int)
         rel = np.abs(sig - ref) / np.abs(ref)
     dec = np.clip(dec, 0, max_dec)
     out = {}
