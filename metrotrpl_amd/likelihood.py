@@ -21,14 +21,18 @@ from . import batch
 class LikelihoodEngine:
     def __init__(self, indexes, units, lengths, nx, meas_types, times, vals, uncs, sigma, iniPar, ini_mode="fluence",
                  model="std", hmax=4.0, rtol=None, atol=None, irf_tables=None, irf_convolution=None,
-                 scale_shift=None, force_min_y=False, device=0, ctx=None, fittables=None, sort_by_cost=True, parts=2):
+                 scale_shift=None, force_min_y=False, device=0, ctx=None, fittables=None, sort_by_cost=True, parts=2,
+                 split_min=2048, sort_min=1024):
         """times/vals/uncs: per-measurement 1-D arrays (as _times/_vals/_uncs of the
         reference's shared fields); sigma: {meas_type: model_uncertainty};
         irf_tables: {wavelength: (table [k,3], t_irf [k])} from make_I_tables;
         irf_convolution: per-measurement wavelength or 0/None; nx: one value or one per
         measurement; fittables: {"fluences"|"absps"|"scale": per-measurement index of the
         state entry that multiplies iniPar[0] / iniPar[1] / sets scale_shift = log10(entry),
-        -1 = none} (trial_move_evaluation.py:38-60, see `fittable_indexes`)."""
+        -1 = none} (trial_move_evaluation.py:38-60, see `fittable_indexes`).
+        parts / split_min: launches of more than split_min solves run as `parts` chain blocks on separate
+        streams; sort_by_cost / sort_min: launches of more than sort_min solves issue the expensive solves
+        of a block first."""
         import torch
         self.torch = torch
         self.dev = torch.device("cuda", device)
@@ -70,8 +74,11 @@ class LikelihoodEngine:
             self.irf_index = [waves.index(int(w)) if w else -1 for w in irf_convolution]
         self.sort_by_cost = bool(sort_by_cost)
         self.parts = max(1, int(parts))
+        self.split_min, self.sort_min = int(split_min), int(sort_min)
         self._side = []
         self._cap = 0
+        self.timing = None  # a list: launch() appends (stream, e0, e1, e2, n_solves) HIP-event triples around
+        #                     the solve and the likelihood kernel of every block (bench.py: roofline)
 
     def _ensure(self, n_solves, nT):
         torch = self.torch
@@ -128,10 +135,10 @@ class LikelihoodEngine:
         # Only the solve descriptors move; outputs keep their places (out_off), the likelihood
         # descriptors and the ll table stay chain-major.
         n = d.shape[0]
-        parts = self.parts if (n > 2048 and self.nx <= 256) else 1
+        parts = self.parts if n > self.split_min else 1
         cuts = [(Cn * p // parts) * self.M for p in range(parts + 1)]
         self._order = None
-        if self.sort_by_cost and n > 1024:
+        if self.sort_by_cost and n > self.sort_min:
             cost = self._measured_cost(n, states)
             if cost is None:  # first launch: the tightened-tolerance solves (tauP >> tauN) are the slow ones
                 tn, tp = st[:, self.indexes["tauN"]], st[:, self.indexes["tauP"]]
@@ -197,14 +204,22 @@ class LikelihoodEngine:
             if p > 0:
                 st.wait_event(fork)
             s = st.cuda_stream
+            if self.timing is not None:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record(st)
             self.ctx.check(lib.mtrpl_solve_batch_dev(h, b - a, self.d_descs.data_ptr() + a * sd, self.d_ini.data_ptr(),
                                                      self.d_t.data_ptr(), self.d_sig.data_ptr(),
                                                      self.d_status.data_ptr() + 4 * a, self.d_stats.data_ptr() + 32 * a,
                                                      self.nx, L.MODEL[self.model], s))
+            if self.timing is not None:
+                ev[1].record(st)
             self.ctx.check(lib.mtrpl_loglik_batch_dev(h, b - a, self.d_like.data_ptr() + a * sl, self.d_sig.data_ptr(),
                                                       self.d_t.data_ptr(), self.d_exp_t.data_ptr(),
                                                       self.d_exp_y.data_ptr(), self.d_exp_u.data_ptr(), d_T.data_ptr(),
                                                       nT, self.max_nt, self.d_ll.data_ptr() + 8 * a * nT, s))
+            if self.timing is not None:
+                ev[2].record(st)
+                self.timing.append((ev[0], ev[1], ev[2], b - a))
             if p > 0:
                 ev = torch.cuda.Event()
                 ev.record(st)

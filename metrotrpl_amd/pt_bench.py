@@ -9,6 +9,7 @@ chain, n_chains x 6 forward solves + IRF convolutions + likelihoods at all ladde
 temperatures on the GPUs, all-gather, accept/reject, and (every temper_freq
 iterations, SURVEY.md 8d: 10) the replica-exchange replay.
 """
+import json
 import os
 import time
 
@@ -47,20 +48,18 @@ def synthetic_data(irf_tables, nx, times):
     return vals, uncs
 
 
-def run(a, rank, world, local, dev):
+def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=True, split_min=2048, sort_min=1024,
+          ctx=None, force_min_y=False):
+    """The config-3/4 problem on one rank: engine, ladder, evaluator and proposer."""
     import torch
-    import torch.distributed as dist
-    n_chains = a.chains
-    nx = 128
     times = W.default_times()
-    ctx = L.default_context(local)
-    irf_tables = laplace.make_I_tables({745: synthetic_irf()})
+    ctx = ctx or L.default_context(local)
+    irf_tables = laplace.make_I_tables({745: synthetic_irf() if irf_raw is None else irf_raw})
     vals, uncs = synthetic_data(irf_tables, nx, times)
     eng = LikelihoodEngine(W.indexes(), W.units(), W.STAUB_LENGTHS, nx, ["TRPL"] * 6, [times] * 6, vals, uncs,
                            {"TRPL": 1.0}, np.array(W.STAUB_FLUENCES), ini_mode="fluence", irf_tables=irf_tables,
-                           irf_convolution=[745] * 6, device=local, ctx=ctx,
-                           sort_by_cost=os.environ.get("MTRPL_NO_SORT") != "1",
-                           parts=int(os.environ.get("MTRPL_PARTS", "2")))
+                           irf_convolution=[745] * 6, device=local, ctx=ctx, sort_by_cost=sort_by_cost, parts=parts,
+                           split_min=split_min, sort_min=sort_min, force_min_y=force_min_y)
     ens0 = W.pt_ensemble(n_chains, nx)
     T = ens0["temperatures"]
     d_T = torch.from_numpy(np.ascontiguousarray(T)).to(dev)
@@ -80,6 +79,42 @@ def run(a, rank, world, local, dev):
     def proposer(states, temps, rng):
         return pt.propose(states, temps, base_move, names, active, prior, do_log, ix, rng)
 
+    return dict(eng=eng, ens0=ens0, T=T, d_T=d_T, evaluator=evaluator, proposer=proposer, times=times, vals=vals,
+                uncs=uncs, irf_tables=irf_tables)
+
+
+def cpu_baseline(S, n_chains_sample=4):
+    """The oracle's eval_trial_move (SciPy LSODA + gcc RHS, IRF convolution and likelihood tail in C) on a
+    bounded sample of the ensemble's chains, one core: proposals per second of the reference's own structure
+    (one process evaluates one chain's proposal: 6 solves + 6 convolutions + the likelihood)."""
+    from oracle import oracle as O
+    O.build()
+    irf = {745: (np.asarray(S["irf_tables"][745][0]), np.asarray(S["irf_tables"][745][1]))}
+    shared = {"_sim_info": {"lengths": list(W.STAUB_LENGTHS), "nx": [128] * 6, "meas_types": ["TRPL"] * 6, "num_meas": 6},
+              "_param_indexes": W.indexes(), "units": W.units(), "_init_params": np.array(W.STAUB_FLUENCES, dtype=float),
+              "_times": [S["times"]] * 6, "_vals": S["vals"], "_uncs": S["uncs"], "hmax": 4.0, "solver": ("solveivp",),
+              "model": "std", "ini_mode": "fluence", "rtol": 1e-7, "atol": 1e-10, "irf_convolution": [745] * 6,
+              "_IRF_tables": irf}
+    uniq = {"model_uncertainty": {"TRPL": 1.0}, "_T": 1.0}
+    states = S["ens0"]["chain_states"]
+    O.eval_trial_move(states[0], uniq, shared, temperatures=S["T"])  # warm-up
+    t0 = time.perf_counter()
+    for k in range(n_chains_sample):
+        O.eval_trial_move(states[k % len(states)], uniq, shared, temperatures=S["T"])
+    dt = time.perf_counter() - t0
+    return {"value": n_chains_sample / dt, "unit": "proposals/s", "cores": 1, "kind": "port",
+            "sample": f"oracle eval_trial_move (6 solves at rtol 1e-7 / atol 1e-10 + 6 IRF convolutions + likelihood at "
+                      f"{len(S['T'])} temperatures) for the first {n_chains_sample} chains of the ensemble, {dt:.1f} s on 1 of "
+                      f"{os.cpu_count()} host cores"}
+
+
+def run(a, rank, world, local, dev):
+    import torch
+    import torch.distributed as dist
+    n_chains = a.chains
+    S = setup(n_chains, dev, local, sort_by_cost=os.environ.get("MTRPL_NO_SORT") != "1",
+              parts=int(os.environ.get("MTRPL_PARTS", "2")))
+    eng, ens0, T, evaluator, proposer = S["eng"], S["ens0"], S["T"], S["evaluator"], S["proposer"]
     ens = pt.PTEnsemble(ens0["chain_states"], T, evaluator, rank=rank, world=world)
     ens.initialise()
     temper_freq = 10
@@ -88,6 +123,7 @@ def run(a, rank, world, local, dev):
         k += 1
         ens.iterate(proposer, k % temper_freq == 0)
     torch.cuda.synchronize()
+    timing = eng.timing = []
     if getattr(a, "use_dist", world > 1):
         dist.barrier()
     torch.cuda.synchronize()
@@ -106,7 +142,7 @@ def run(a, rank, world, local, dev):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     stats = eng.d_stats.cpu().numpy().reshape(-1, 8)
-    return {
+    line = {
         "metric": "mcmc_proposals_per_sec", "value": n_chains * a.steps / dt, "unit": "proposals/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -116,5 +152,55 @@ def run(a, rank, world, local, dev):
                    "chains": n_chains, "solves_per_step": n_chains * 6, "parallelism": f"chain-blocks x{world}",
                    "forward_solves_per_sec": n_chains * 6 * a.steps / dt, "accepted_moves": n_acc,
                    "swap_accept_rate": float(ens.swap_accepts.sum() / max(1, ens.swap_attempts.sum())),
-                   "mean_integrator_steps_rank0": float(stats[:, 0].mean())},
+                   "mean_integrator_steps_rank0": float(stats[:, 0].mean()),
+                   "max_integrator_steps_rank0": int(stats[:, 0].max())},
     }
+    if rank == 0:
+        # roofline of the dominant kernel (the forward solve) from the HIP events recorded around every
+        # solve launch of the timed iterations, on the stream it was launched on
+        A = algorithmic_bytes(128, len(S["times"]), irf_nk=80000)
+        t_solve = [e0.elapsed_time(e1) for e0, e1, e2, n in timing]
+        t_like = [e1.elapsed_time(e2) for e0, e1, e2, n in timing]
+        n_solve = [n for *_, n in timing]
+        kern_ms = float(np.mean(t_solve))
+        achieved = A * float(np.mean(n_solve)) / (kern_ms * 1e-3) / 1e9
+        line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBS, "kernel": "solve_kernel_wave", "kernel_ms": kern_ms,
+                            "solves_per_launch": float(np.mean(n_solve)), "launches_per_step": len(timing) / max(1, a.steps),
+                            "algorithmic_bytes_per_solve": A, "loglik_kernel_ms": float(np.mean(t_like)),
+                            **pmc_fields(),
+                            "note": "state-streaming model of SURVEY.md 8d incl. the 8*(3*nk+2) IRF term; the solve state "
+                                    "is register-resident by design, so HBM is not the limiter (DESIGN.md section 4)"}
+        if world == 1 and not getattr(a, "no_cpu_baseline", False):
+            line["cpu_baseline"] = cpu_baseline(S)
+    return line
+
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(nx, nt, model="std", irf_nk=0):
+    """A = nt_out * 8 * (2S + 1), S = 3nx+1 (std) / 4nx+1 (traps); + 8*(3*nk+2) with IRF on."""
+    S_ = (3 if model == "std" else 4) * nx + 1
+    a = nt * 8 * (2 * S_ + 1)
+    if irf_nk:
+        a += 8 * (3 * irf_nk + 2)
+    return a
+
+
+def pmc_fields():
+    """Counter-derived figures of the solve kernel from the committed rocprofv3 --pmc summary (they are not
+    measured in this run; traffic_source says where they come from)."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tp = os.path.join(repo, "profiles", "hbm_traffic.json")
+    out = {"traffic": None, "traffic_source": None}
+    try:
+        z = json.load(open(tp))
+        out["traffic"] = z.get("solve_kernel_bytes_per_launch")
+        out["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the config-2 launch)"
+        d = z.get("derived", {})
+        out["valu_active_frac"] = d.get("valu_active_fraction_of_wave_cycles")
+        out["occupancy_waves_per_simd"] = d.get("occupancy_waves_per_simd", 1)
+    except Exception:
+        pass
+    return out

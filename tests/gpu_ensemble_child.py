@@ -1,0 +1,58 @@
+"""Child process of tests/test_gpu_ensemble.py: the config-3 parallel-tempering ensemble (64 chains x the
+6-measurement staub power scan, nx=128, 1001 sample times, IRF 745 nm) for a few iterations on cuda:0,
+optionally inside a one-rank `nccl` process group that is initialised BEFORE anything touches the GPU, so
+that the per-iteration all-gather of the log-likelihood table really goes through RCCL.
+Writes the walk to an .npz.  Not a test by itself."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dist", type=int, default=0)
+    ap.add_argument("--parts", type=int, default=1)
+    ap.add_argument("--sort", type=int, default=0)
+    ap.add_argument("--chains", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=12)
+    ap.add_argument("--temper-freq", type=int, default=5)
+    ap.add_argument("--port", type=int, default=29617)
+    ap.add_argument("--force-min-y", type=int, default=1)
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", 0)
+    if a.dist:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{a.port}", rank=0, world_size=1, device_id=dev)
+    torch.cuda.set_device(0)
+    from metrotrpl_amd import pt, pt_bench
+    irf_raw = np.load(os.path.join(REPO, "tests", "golden", "irf.npz"))["irf745_raw"]
+    S = pt_bench.setup(a.chains, dev, 0, irf_raw=irf_raw, parts=a.parts, sort_by_cost=bool(a.sort), split_min=0,
+                       sort_min=0, force_min_y=bool(a.force_min_y))
+    ens = pt.PTEnsemble(S["ens0"]["chain_states"], S["T"], S["evaluator"], rank=0, world=1)
+    ens.initialise()
+    table0 = ens.table.copy()
+    n_parts = len(S["eng"]._cuts) - 1
+    swaps = 0
+    for k in range(1, a.iters + 1):
+        do_swap = k % a.temper_freq == 0
+        swaps += int(do_swap)
+        ens.iterate(S["proposer"], do_swap)
+    torch.cuda.synchronize()
+    backend = dist.get_backend() if (a.dist and dist.is_initialized()) else "none"
+    np.savez(a.out, states0=S["ens0"]["chain_states"], table0=table0, states=ens.states, logll=ens.logll, table=ens.table,
+             swap_attempts=ens.swap_attempts, swap_accepts=ens.swap_accepts, T=S["T"], times=S["times"],
+             vals=np.array(S["vals"]), uncs=np.array(S["uncs"]), n_parts=n_parts, swaps=swaps, backend=np.array(backend),
+             ordered=np.array(S["eng"]._order is not None))
+    if a.dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
