@@ -112,14 +112,14 @@ struct PairBackend {
     }
     __device__ inline void emit_pending(double t0, double t1, double t2, double t3)
     {
-        // wave 0 holds the emitter state; totals are own wave sum + the other wave's
+        // totals are own wave sum + the other wave's (a + b == b + a: both waves see the same values and
+        // keep the same emitter state); lane 0 of wave 0 stores
         // (static register indices only: a run-time index would send the record to scratch memory)
-        if (wave == 0) {
-            if (n_pend > 0) em.put(io_first, pend[0] + t0, p.dx, lane == 0);
-            if (n_pend > 1) em.put(io_first + 1, pend[1] + t1, p.dx, lane == 0);
-            if (n_pend > 2) em.put(io_first + 2, pend[2] + t2, p.dx, lane == 0);
-            if (n_pend > 3) em.put(io_first + 3, pend[3] + t3, p.dx, lane == 0);
-        }
+        const bool writer = (wave == 0) && (lane == 0);
+        if (n_pend > 0) em.put(io_first, pend[0] + t0, p.dx, writer);
+        if (n_pend > 1) em.put(io_first + 1, pend[1] + t1, p.dx, writer);
+        if (n_pend > 2) em.put(io_first + 2, pend[2] + t2, p.dx, writer);
+        if (n_pend > 3) em.put(io_first + 3, pend[3] + t3, p.dx, writer);
         n_pend = 0;
     }
 
@@ -175,7 +175,8 @@ struct PairBackend {
         }
         return v;
     }
-    __device__ inline void out_begin(double *o, double min_y, double scale) { em.begin(o, min_y, scale); }
+    __device__ inline void out_begin(double *o, double min_y, double scale, double deep) { em.begin(o, min_y, scale, deep); }
+    __device__ inline bool deep() const { return em.deep; }
     __device__ inline void flush()
     {
         const double mine[4] = {pend[0], pend[1], pend[2], pend[3]};

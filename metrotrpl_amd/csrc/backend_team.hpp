@@ -142,7 +142,8 @@ struct TeamBackend {
         }
         return v;
     }
-    __device__ inline void out_begin(double *o, double min_y, double scale) { em.begin(o, min_y, scale); }
+    __device__ inline void out_begin(double *o, double min_y, double scale, double deep) { em.begin(o, min_y, scale, deep); }
+    __device__ inline bool deep() const { return em.deep; }
     __device__ inline void out_sample(int k, real partial)
     {
         // full-precision sum (reduce() is the controller-grade one)

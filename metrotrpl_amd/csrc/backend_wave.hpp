@@ -69,7 +69,8 @@ struct WaveBackend {
     }
     __device__ inline double scan_excl(double run) const { return wave_scan_incl(run, lane) - run; }
     __device__ inline double max_all(double v) const { return wave_max(v); }
-    __device__ inline void out_begin(double *o, double min_y, double scale) { em.begin(o, min_y, scale); }
+    __device__ inline void out_begin(double *o, double min_y, double scale, double deep) { em.begin(o, min_y, scale, deep); }
+    __device__ inline bool deep() const { return em.deep; }
     __device__ inline void out_sample(int k, double partial) { em.put(k, uniform(wave_sum(partial)), p.dx, lane == 0); }
     __device__ inline void out_finish() {}
 

@@ -73,6 +73,7 @@ struct SolveTuning {
     double rate_first_safety;  // > 0: after a refactorisation carry (this x first measured rate); 0: VODE smoothing only
     double e_weight;    // relative error weight of the field components = e_weight * rtol_int (TRPL solves)
     int honor_hmax;     // 1: desc.hmax caps the step (the reference's max_step); 0: error control alone
+    double hmax_deep;   // ... until the signal has fallen below this fraction of its first sample (0: always)
     double trts_rtol_factor;  // internal rtol of TRTS solves = this x that of TRPL solves
     double amp_ref;           // > 0: internal rtol /= max(1, (1 + tauP/tauN) / amp_ref); 0: off
     double nq_deadband_hi;    // a step factor in [0.9, this) keeps h and the factors
@@ -176,12 +177,20 @@ __device__ inline void nq_dense(const T (&z)[6][V], T s, T (&yq)[V])
 struct Emitter {
     double *o;
     double min_y, scale;
-    bool clamped;
-    __device__ inline void begin(double *o_, double min_y_, double scale_) { o = o_; min_y = min_y_; scale = scale_; clamped = false; }
-    // total = dx-less grid sum; writer = this thread stores
+    double deep_below;  // deep_frac x the first sample
+    bool clamped, deep;
+    __device__ inline void begin(double *o_, double min_y_, double scale_, double deep_frac)
+    {
+        o = o_; min_y = min_y_; scale = scale_; clamped = false; deep = false;
+        deep_below = -deep_frac;  // negative until the first sample fixes the scale
+    }
+    // total = dx-less grid sum; writer = this thread stores.  Every thread that calls sees the same v,
+    // so `deep` is uniform among the callers.
     __device__ inline void put(int k, double total, double dx, bool writer)
     {
         double v = total * dx * scale;
+        if (deep_below < 0.0) deep_below = -deep_below * fabs(v);
+        else if (!(fabs(v) >= deep_below)) deep = true;
         if (!clamped && v < min_y) clamped = true;
         if (clamped) v = min_y;
         if (writer) o[k] = v;
@@ -204,7 +213,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
     const double *ts = tsteps + ds.t_off;
     const real hmax = tune.honor_hmax ? (real)ds.hmax : big<real>();
     const real inv_S = (real)(1.0 / (double)((TRAPS ? 4 : 3) * L + 1));
-    bk.out_begin(out + ds.out_off, ds.min_y, (meas == MTRPL_MEAS_TRPL) ? 1e23 : 1e9);  // forward_solver.py:189,:197
+    bk.out_begin(out + ds.out_off, ds.min_y, (meas == MTRPL_MEAS_TRPL) ? 1e23 : 1e9, tune.hmax_deep);  // forward_solver.py:189,:197
 
     // ---- initial condition, forward_solver.py:100-122 ----
     real y[V];
@@ -573,7 +582,9 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         // a step that was rejected a moment ago says the estimates behind `fac` are optimistic here (stiff
         // surface terms): grow cautiously for a while instead of hunting (reject / shrink / regrow / reject)
         if (since_rej < tune.nq_rej_memory) fac = fmin(fac, (real)tune.nq_rej_growth);
-        if (h * fac > hmax) fac = hmax * ih;
+        // max_step guards LSODA against stepping over structure; once the signal is down in the rounding noise
+        // of N P - n0 p0 (hmax_deep, 11 decades by default) there is none left and the error test alone decides
+        if (h * fac > hmax && !bk.deep()) fac = hmax * ih;
         if (dorder == 0 && fac >= (real)0.9 && fac < (real)tune.nq_deadband_hi) {
             n_equal = order - 2;  // keep h and the factors; test again three steps on
             continue;

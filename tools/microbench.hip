@@ -30,7 +30,7 @@ __device__ inline void body(BK &bk, double *out, long long *cyc, int iters)
     bk.build(y, 0.1, 0.1);
     double acc = 0.0;
     __shared__ double sink[1024];
-    bk.out_begin(sink, 0.0, 1.0);
+    bk.out_begin(sink, 0.0, 1.0, 0.0);
     long long t0, t1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     for (int it = 0; it < iters; ++it) {
