@@ -38,7 +38,8 @@ struct WaveBackend {
     double2 *lds;
     enum { BINV_E = 0, BIA_E, BIC_E, CR_AL, CR_GA, PAL0, PGA0 = PAL0 + 6, NBLK = PGA0 + 6 };
 
-    __device__ inline WaveBackend(int lane_, double2 *lds_) : lane(lane_), lds(lds_) {}
+    int lds_off;  // lane * 16: byte offset of this lane's 16-byte row inside a block row
+    __device__ inline WaveBackend(int lane_, double2 *lds_) : lane(lane_), lds(lds_), lds_off(lane_ * 16) {}
     __device__ inline void set_problem(const ParT<real> &p_, int L_) { p = p_; L = L_; }
     __device__ inline int node(int r) const { return lane * R + r; }
     __device__ inline bool leader() const { return lane == 0; }
@@ -48,14 +49,16 @@ struct WaveBackend {
         lds[(blk * 2 + 0) * 64 + lane] = double2{m.a, m.b};
         lds[(blk * 2 + 1) * 64 + lane] = double2{m.c, m.d};
     }
-    __device__ inline M2 get(int blk) const
+    __device__ inline M2 get(int blk)
     {
-        // Opaque lane index: keeps the block loads inside the Newton loop (16-B rows re-read from LDS
+        // Opaque row offset: keeps the block loads inside the Newton loop (16-B rows re-read from LDS
         // every iteration) instead of letting the compiler hoist 64+ VGPRs of loop-invariant blocks and
         // push the history out to AGPRs (measured: AGPRs 256 -> 116, 12.8 -> 12.3 ms per 1024-solve batch).
-        int l_ = lane;
-        asm volatile("" : "+v"(l_));
-        const double2 u = lds[(blk * 2 + 0) * 64 + l_], v = lds[(blk * 2 + 1) * 64 + l_];
+        // The offset register itself is declared modified, so hiding it costs no instruction.
+        asm volatile("" : "+v"(lds_off));
+        const char *base = reinterpret_cast<const char *>(lds) + lds_off;
+        const double2 u = *reinterpret_cast<const double2 *>(base + (blk * 2 + 0) * 1024);
+        const double2 v = *reinterpret_cast<const double2 *>(base + (blk * 2 + 1) * 1024);
         return M2{u.x, u.y, v.x, v.y};
     }
 
@@ -188,9 +191,15 @@ struct WaveBackend {
             const int s = 1 << lv;
             const int lm_ = (lane - s) & 63, lp_ = (lane + s) & 63;
             const M2 Bi = minv(Bk);
-            const M2 Bim = mshf(Bi, lm_), Bip = mshf(Bi, lp_);
-            const M2 Akm = mshf(Ak, lm_), Akp = mshf(Ak, lp_);
-            const M2 Ckm = mshf(Ck, lm_), Ckp = mshf(Ck, lp_);
+            M2 Bim, Bip, Akm, Akp, Ckm, Ckp;
+            if (lv == 0) {
+                Bim = mprev(Bi); Bip = mnext(Bi); Akm = mprev(Ak); Akp = mnext(Ak); Ckm = mprev(Ck); Ckp = mnext(Ck);
+            } else if (lv == 5) {
+                mswap32(Bi, Bim, Bip); mswap32(Ak, Akm, Akp); mswap32(Ck, Ckm, Ckp);
+            } else {
+                Bim = mshf(Bi, lm_); Bip = mshf(Bi, lp_); Akm = mshf(Ak, lm_); Akp = mshf(Ak, lp_);
+                Ckm = mshf(Ck, lm_); Ckp = mshf(Ck, lp_);
+            }
             const M2 al = mmul(Ak, Bim), ga = mmul(Ck, Bip);
             put(PAL0 + lv, al);
             put(PGA0 + lv, ga);
@@ -202,7 +211,7 @@ struct WaveBackend {
     }
 
     // x = M^{-1} b; b, x in lane layout [N0,N1,P0,P1,E0,E1]
-    __device__ inline void apply(const double (&b)[V], double (&x)[V]) const
+    __device__ inline void apply(const double (&b)[V], double (&x)[V])
     {
         // E-elimination right-hand side
         V2 wb[3];
@@ -222,8 +231,16 @@ struct WaveBackend {
 #pragma unroll
         for (int lv = 0; lv < 6; ++lv) {
             const int s = 1 << lv;
-            const V2 rm = vshf(rk, (lane - s) & 63);
-            const V2 rp = vshf(rk, (lane + s) & 63);
+            V2 rm, rp;
+            if (lv == 0) {          // nearest neighbours: DPP wave shifts
+                rm = vprev(rk);
+                rp = vnext(rk);
+            } else if (lv == 5) {   // stride 32: v_permlane32_swap, no LDS round trip
+                vswap32(rk, rm, rp);
+            } else {
+                rm = vshf(rk, (lane - s) & 63);
+                rp = vshf(rk, (lane + s) & 63);
+            }
             const V2 u1 = mvec(get(PAL0 + lv), rm), u2 = mvec(get(PGA0 + lv), rp);
             rk = V2{rk.x - u1.x - u2.x, rk.y - u1.y - u2.y};
         }

@@ -77,6 +77,23 @@ __device__ inline T dppz(T v)
 template <class T> __device__ inline T from_prev(T v) { return dppz<0x138>(v); }  // wave_shr:1: lane i <- lane i-1
 template <class T> __device__ inline T from_next(T v) { return dppz<0x130>(v); }  // wave_shl:1: lane i <- lane i+1
 
+// Stride-32 exchange without LDS: one v_permlane32_swap per dword (gfx950) yields BOTH neighbours --
+// `dn` holds the value of lane-32 in lanes 32..63, `up` the value of lane+32 in lanes 0..31; the other
+// halves keep the lane's own value (finite: where that is read it meets a zero block).
+template <class T> __device__ inline void swap32(T v, T &dn, T &up)
+{
+    union { T d; unsigned i[sizeof(T) / 4]; } u, a, b;
+    u.d = v;
+#pragma unroll
+    for (unsigned k = 0; k < sizeof(T) / 4; ++k) {
+        const auto r = __builtin_amdgcn_permlane32_swap(u.i[k], u.i[k], false, false);
+        a.i[k] = r[0];
+        b.i[k] = r[1];
+    }
+    dn = a.d;
+    up = b.d;
+}
+
 // Sum over the 64 lanes, result wave-uniform (in SGPRs).  gfx9 DPP ladder: row_shr 1,2,4,8 inside
 // each row of 16 (sources outside the row read as 0), then row_bcast15 / row_bcast31 carry the row
 // totals forward; the grand total lands in lane 63.
@@ -172,6 +189,14 @@ template <class T> __device__ inline V2T<T> mvec(const M2T<T> &m, const V2T<T> &
 // last rows vanish, and stay zero through every reduction level), so it contributes exactly 0.
 template <class T> __device__ inline M2T<T> mshf(const M2T<T> &m, int src) { return M2T<T>{shf(m.a, src), shf(m.b, src), shf(m.c, src), shf(m.d, src)}; }
 template <class T> __device__ inline V2T<T> vshf(const V2T<T> &v, int src) { return V2T<T>{shf(v.x, src), shf(v.y, src)}; }
+template <class T> __device__ inline void mswap32(const M2T<T> &m, M2T<T> &dn, M2T<T> &up)
+{
+    swap32(m.a, dn.a, up.a); swap32(m.b, dn.b, up.b); swap32(m.c, dn.c, up.c); swap32(m.d, dn.d, up.d);
+}
+template <class T> __device__ inline void vswap32(const V2T<T> &v, V2T<T> &dn, V2T<T> &up)
+{
+    swap32(v.x, dn.x, up.x); swap32(v.y, dn.y, up.y);
+}
 template <class T> __device__ inline M2T<T> mnext(const M2T<T> &m) { return M2T<T>{from_next(m.a), from_next(m.b), from_next(m.c), from_next(m.d)}; }
 template <class T> __device__ inline M2T<T> mprev(const M2T<T> &m) { return M2T<T>{from_prev(m.a), from_prev(m.b), from_prev(m.c), from_prev(m.d)}; }
 template <class T> __device__ inline V2T<T> vnext(const V2T<T> &v) { return V2T<T>{from_next(v.x), from_next(v.y)}; }

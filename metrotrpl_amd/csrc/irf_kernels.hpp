@@ -634,6 +634,13 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
     __shared__ int s_cnt[2];
     double *work = GWORK ? gwork + (size_t)blockIdx.x * 6 * (size_t)max_nt : smem;
     double *irfw = GWORK ? smem : smem + 6 * (size_t)max_nt;
+    if (!GWORK) {  // one block per trace
+        const int64_t sidx = blockIdx.x;
+        if (sidx < B)
+            loglik_trace(descs[sidx], sidx, sig, tsteps, exp_t, exp_y, exp_u, temps, nT, max_nt, tables, set, neg_frac_tol,
+                         ll, work, irfw, red_v, red_i, s_cnt);
+        return;
+    }
     for (int64_t sidx = blockIdx.x; sidx < B; sidx += gridDim.x) {
         loglik_trace(descs[sidx], sidx, sig, tsteps, exp_t, exp_y, exp_u, temps, nT, max_nt, tables, set, neg_frac_tol,
                      ll, work, irfw, red_v, red_i, s_cnt);

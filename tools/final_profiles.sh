@@ -1,21 +1,27 @@
 #!/bin/bash
 # tools/final_profiles.sh TAG -- the bench / rocprofv3 / PMC set that profiles/ holds for a round (run on the GPU box via gpurun)
-set -e
 T=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out
-timeout -k 10 280 python bench.py --steps 30 --warmup 3 > $O/${T}_bench_config2.json 2> $O/${T}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_$T.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc${T}_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc${T}1.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc${T}_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc${T}2.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc${T}_sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc${T}3.log 2>&1
-python tools/pmc_summary.py solve_kernel_nq $O/hbm_traffic_$T.json $O/pmc${T}_fetch $O/pmc${T}_write $O/pmc${T}_sq | tail -9
-timeout -k 10 200 python bench.py --workload pt --chains 512 --steps 12 --warmup 3 > $O/${T}_bench_pt512_1gpu.json
-timeout -k 10 200 python bench.py --workload pt --chains 64 --steps 12 --warmup 3 > $O/${T}_bench_pt64_1gpu.json
-timeout -k 10 100 python bench.py --no-cpu-baseline --steps 12 --streams 2 > $O/${T}_bench_streams2.json
-timeout -k 10 100 python bench.py --no-cpu-baseline --steps 12 --streams 2 --batch 2048 > $O/${T}_bench_streams2_b2048.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${T}pt -- python3 bench.py --workload pt --chains 512 --steps 5 --warmup 1 > $O/prof_${T}pt.log 2>&1
+BENCH="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+timeout -k 10 400 python bench.py --steps 30 --warmup 3 > $O/${T}_bench_config2.json 2> $O/${T}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -- $BENCH > $O/prof_$T.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc${T}_fetch -- $BENCH > $O/pmc${T}1.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc${T}_write -- $BENCH > $O/pmc${T}2.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc${T}_sq -- $BENCH > $O/pmc${T}3.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/pmc${T}_sq2 -- $BENCH > $O/pmc${T}4.log 2>&1
+python tools/pmc_summary.py solve_kernel_wave $O/hbm_traffic_$T.json $O/pmc${T}_fetch $O/pmc${T}_write $O/pmc${T}_sq $O/pmc${T}_sq2 | tail -12
+timeout -k 10 300 python bench.py --workload pt --chains 512 --steps 12 --warmup 3 > $O/${T}_bench_pt512_1gpu.json 2>> $O/${T}_bench.err
+timeout -k 10 300 python bench.py --workload pt --chains 64 --steps 12 --warmup 3 > $O/${T}_bench_pt64_1gpu.json 2>> $O/${T}_bench.err
+timeout -k 10 100 python bench.py --no-cpu-baseline --steps 12 --streams 2 > $O/${T}_bench_streams2.json 2>> $O/${T}_bench.err
+timeout -k 10 100 python bench.py --no-cpu-baseline --steps 12 --streams 2 --batch 2048 > $O/${T}_bench_streams2_b2048.json 2>> $O/${T}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${T}pt -- python3 bench.py --workload pt --chains 512 --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_${T}pt.log 2>&1
 cp $O/prof_$T/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_config2.csv
 cp $O/prof_${T}pt/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_pt512.csv
-cut -c1-160 $O/${T}_bench_*.json
-head -2 $O/${T}_kernel_stats_bench_config2.csv | cut -c1-200
+timeout -k 10 200 python tools/tail_table.py --json $O/${T}_tail_decades.json --settings shipped > $O/${T}_tail_decades.txt 2>/dev/null
+timeout -k 10 200 python tools/stamps.py --variant 2,4 --batch 1024 > $O/${T}_stamps.txt 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -o $O/microbench tools/microbench.hip 2>/dev/null && timeout -k 5 120 $O/microbench 256 > $O/${T}_microbench.txt 2>&1; rm -f $O/microbench
+timeout -k 10 100 python tools/solve_latency.py > $O/${T}_solve_latency.txt 2>/dev/null
+cut -c1-200 $O/${T}_bench_*.json
+head -3 $O/${T}_kernel_stats_bench_config2.csv | cut -c1-200
+cat $O/${T}_solve_latency.txt

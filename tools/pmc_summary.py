@@ -21,7 +21,7 @@ for d in sys.argv[3:]:
             vals[c] = sum(v) / len(v)  # average per launch
 fetch, write = vals.get("FETCH_SIZE"), vals.get("WRITE_SIZE")
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, --kernel-trace only) on "
-                 "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline`; kernel " + kern + ", average per launch (1024 solves)",
+                 "`python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`; kernel " + kern + ", average per launch (1024 solves)",
        "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
        "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE reports 1/2 of a wide coalesced read on gfx950 -> doubled; "
                      "WRITE_SIZE exact; both in KiB.  Reads here are small descriptor/time-grid loads, so the factor is an upper bound.",
@@ -31,9 +31,16 @@ res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (se
 sq = res["sq_counters_per_launch"]
 if "SQ_WAVES" in sq:
     w = sq["SQ_WAVES"]
+    wc = sq.get("SQ_WAVE_CYCLES") or None
+    frac = lambda k: (sq[k] / wc) if (wc and k in sq) else None
     res["derived"] = {"valu_insts_per_solve": sq.get("SQ_INSTS_VALU", 0) / w, "salu_insts_per_solve": sq.get("SQ_INSTS_SALU", 0) / w,
                       "lds_insts_per_solve": sq.get("SQ_INSTS_LDS", 0) / w,
-                      "valu_active_fraction_of_wave_cycles": sq.get("SQ_ACTIVE_INST_VALU", 0) / sq["SQ_WAVE_CYCLES"] if sq.get("SQ_WAVE_CYCLES") else None,
+                      "valu_active_fraction_of_wave_cycles": frac("SQ_ACTIVE_INST_VALU"),
+                      "lds_active_fraction_of_wave_cycles": frac("SQ_ACTIVE_INST_LDS"),
+                      "scalar_active_fraction_of_wave_cycles": frac("SQ_ACTIVE_INST_SCA"),
+                      "parked_on_waitcnt_fraction_of_wave_cycles": frac("SQ_WAIT_ANY"),
+                      "issue_stall_fraction_of_wave_cycles": frac("SQ_WAIT_INST_ANY"),
+                      "occupancy_waves_per_simd": 1,
                       "wave_cycles_per_solve(quad-cycles*4)": 4 * sq.get("SQ_WAVE_CYCLES", 0) / w}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
