@@ -102,6 +102,32 @@ def cpu_baseline(sample=48):
     return out
 
 
+def cpu_baseline_pt(S, n_chains_sample=4):
+    """The oracle's eval_trial_move (SciPy LSODA + gcc RHS, IRF convolution and likelihood tail in C) on a
+    bounded sample of the ensemble's chains, one core: proposals per second of the reference's own structure
+    (one process evaluates one chain's proposal: 6 solves + 6 convolutions + the likelihood)."""
+    from metrotrpl_amd import workloads as W
+    from oracle import oracle as O
+    O.build()
+    irf = {745: (np.asarray(S["irf_tables"][745][0]), np.asarray(S["irf_tables"][745][1]))}
+    shared = {"_sim_info": {"lengths": list(W.STAUB_LENGTHS), "nx": [128] * 6, "meas_types": ["TRPL"] * 6, "num_meas": 6},
+              "_param_indexes": W.indexes(), "units": W.units(), "_init_params": np.array(W.STAUB_FLUENCES, dtype=float),
+              "_times": [S["times"]] * 6, "_vals": S["vals"], "_uncs": S["uncs"], "hmax": 4.0, "solver": ("solveivp",),
+              "model": "std", "ini_mode": "fluence", "rtol": 1e-7, "atol": 1e-10, "irf_convolution": [745] * 6,
+              "_IRF_tables": irf}
+    uniq = {"model_uncertainty": {"TRPL": 1.0}, "_T": 1.0}
+    states = S["ens0"]["chain_states"]
+    O.eval_trial_move(states[0], uniq, shared, temperatures=S["T"])  # warm-up
+    t0 = time.perf_counter()
+    for k in range(n_chains_sample):
+        O.eval_trial_move(states[k % len(states)], uniq, shared, temperatures=S["T"])
+    dt = time.perf_counter() - t0
+    return {"value": n_chains_sample / dt, "unit": "proposals/s", "cores": 1, "kind": "port",
+            "sample": f"oracle eval_trial_move (6 solves at rtol 1e-7 / atol 1e-10 + 6 IRF convolutions + likelihood at "
+                      f"{len(S['T'])} temperatures) for the first {n_chains_sample} chains of the ensemble, {dt:.1f} s on 1 of "
+                      f"{os.cpu_count()} host cores"}
+
+
 def _cpu_one(k):
     os.environ["OPENBLAS_NUM_THREADS"] = "1"
     from metrotrpl_amd import workloads as W
@@ -163,7 +189,7 @@ def main():
     from metrotrpl_amd import _lib as L, batch, workloads as W
     if a.workload == "pt":
         from metrotrpl_amd import pt_bench
-        line = pt_bench.run(a, rank, world, local, dev)
+        line = pt_bench.run(a, rank, world, local, dev, cpu_baseline_fn=cpu_baseline_pt)
         if rank == 0:
             print(json.dumps(line))
         if use_dist:

@@ -83,32 +83,7 @@ def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=Tr
                 uncs=uncs, irf_tables=irf_tables)
 
 
-def cpu_baseline(S, n_chains_sample=4):
-    """The oracle's eval_trial_move (SciPy LSODA + gcc RHS, IRF convolution and likelihood tail in C) on a
-    bounded sample of the ensemble's chains, one core: proposals per second of the reference's own structure
-    (one process evaluates one chain's proposal: 6 solves + 6 convolutions + the likelihood)."""
-    from oracle import oracle as O
-    O.build()
-    irf = {745: (np.asarray(S["irf_tables"][745][0]), np.asarray(S["irf_tables"][745][1]))}
-    shared = {"_sim_info": {"lengths": list(W.STAUB_LENGTHS), "nx": [128] * 6, "meas_types": ["TRPL"] * 6, "num_meas": 6},
-              "_param_indexes": W.indexes(), "units": W.units(), "_init_params": np.array(W.STAUB_FLUENCES, dtype=float),
-              "_times": [S["times"]] * 6, "_vals": S["vals"], "_uncs": S["uncs"], "hmax": 4.0, "solver": ("solveivp",),
-              "model": "std", "ini_mode": "fluence", "rtol": 1e-7, "atol": 1e-10, "irf_convolution": [745] * 6,
-              "_IRF_tables": irf}
-    uniq = {"model_uncertainty": {"TRPL": 1.0}, "_T": 1.0}
-    states = S["ens0"]["chain_states"]
-    O.eval_trial_move(states[0], uniq, shared, temperatures=S["T"])  # warm-up
-    t0 = time.perf_counter()
-    for k in range(n_chains_sample):
-        O.eval_trial_move(states[k % len(states)], uniq, shared, temperatures=S["T"])
-    dt = time.perf_counter() - t0
-    return {"value": n_chains_sample / dt, "unit": "proposals/s", "cores": 1, "kind": "port",
-            "sample": f"oracle eval_trial_move (6 solves at rtol 1e-7 / atol 1e-10 + 6 IRF convolutions + likelihood at "
-                      f"{len(S['T'])} temperatures) for the first {n_chains_sample} chains of the ensemble, {dt:.1f} s on 1 of "
-                      f"{os.cpu_count()} host cores"}
-
-
-def run(a, rank, world, local, dev):
+def run(a, rank, world, local, dev, cpu_baseline_fn=None):
     import torch
     import torch.distributed as dist
     n_chains = a.chains
@@ -171,8 +146,8 @@ def run(a, rank, world, local, dev):
                             **pmc_fields(),
                             "note": "state-streaming model of SURVEY.md 8d incl. the 8*(3*nk+2) IRF term; the solve state "
                                     "is register-resident by design, so HBM is not the limiter (DESIGN.md section 4)"}
-        if world == 1 and not getattr(a, "no_cpu_baseline", False):
-            line["cpu_baseline"] = cpu_baseline(S)
+        if cpu_baseline_fn is not None and world == 1 and not getattr(a, "no_cpu_baseline", False):
+            line["cpu_baseline"] = cpu_baseline_fn(S)  # the oracle lives outside the package (bench.py)
     return line
 
 

@@ -81,4 +81,4 @@ def test_only_tests_smoke_and_cpu_baseline_touch_the_oracle():
         j = i
         while not src[j].startswith("def "):
             j -= 1
-        assert src[j].startswith("def cpu_baseline") or src[j].startswith("def _cpu_one"), src[j]
+        assert src[j].startswith(("def cpu_baseline", "def cpu_baseline_pt", "def _cpu_one")), src[j]

@@ -21,6 +21,7 @@ cp $O/prof_${T}pt/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_pt512.csv
 timeout -k 10 200 python tools/tail_table.py --json $O/${T}_tail_decades.json --settings shipped > $O/${T}_tail_decades.txt 2>/dev/null
 timeout -k 10 200 python tools/stamps.py --variant 2,4 --batch 1024 > $O/${T}_stamps.txt 2>/dev/null
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -o $O/microbench tools/microbench.hip 2>/dev/null && timeout -k 5 120 $O/microbench 256 > $O/${T}_microbench.txt 2>&1; rm -f $O/microbench
+timeout -k 10 600 python tools/config5_sweep.py $O/${T}_config5_sweep.json > $O/${T}_config5_sweep.txt 2>/dev/null
 timeout -k 10 100 python tools/solve_latency.py > $O/${T}_solve_latency.txt 2>/dev/null
 cut -c1-200 $O/${T}_bench_*.json
 head -3 $O/${T}_kernel_stats_bench_config2.csv | cut -c1-200

@@ -8,7 +8,9 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(REPO, "metrotrpl_amd", "lib", "libmetrotrpl_amd_stamps.so")
-if not os.path.exists(LIB) or os.environ.get("MTRPL_STAMPS_REBUILD"):
+CSRC = os.path.join(REPO, "metrotrpl_amd", "csrc")
+_newest = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC))
+if not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest or os.environ.get("MTRPL_STAMPS_REBUILD"):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                            "-DMTRPL_STAMPS", "-o", LIB, os.path.join(REPO, "metrotrpl_amd", "csrc", "mtrpl_capi.hip")])
 os.environ["MTRPL_LIB_PATH"] = LIB
