@@ -46,8 +46,10 @@
 #define MTRPL_STAMP(acc) do { } while (0)
 #endif
 
-// `order` is wave-uniform, so a scalar switch picks one of five fully static bodies: no per-row
-// predication, and every z[k][v] has a fixed register.
+// `order` is wave-uniform.  The Nordsieck rows above the current order are kept at exactly zero, so every
+// VECTOR operation on the history (Pascal predictor, retraction, rescaling, Horner interpolation) is the
+// order-5 one whatever the order is -- one body, no joins of 36-register arrays behind a five-way switch --
+// and the order only selects SCALAR coefficients, through this switch:
 #define MTRPL_ORDER_SWITCH(order_, CALL)               \
     switch (order_) {                                   \
         case 1: { constexpr int K = 1; CALL; } break;   \
@@ -147,6 +149,15 @@ __device__ inline void nq_correct(T (&z)[6][V], const T (&acor)[V])
     for (int j = 0; j <= K; ++j)
 #pragma unroll
         for (int v = 0; v < V; ++v) z[j][v] += (T)Tb.el[K][j] * acor[v];
+}
+// the same with the l-vector of a run-time order (zero above it): rows above the order stay zero
+template <int V, class T>
+__device__ inline void nq_correct_rt(T (&z)[6][V], const T (&acor)[V], const T (&el)[6])
+{
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int v = 0; v < V; ++v) z[j][v] += el[j] * acor[v];
 }
 // z[j] *= eta^j
 template <int K, int V, class T>
@@ -401,7 +412,8 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             const bool will_select = n_equal >= order;
             // predictor: z <- A z; z[0] is the predicted state, z[1] the predicted h*y'
             real el0 = (real)1, inv_t2 = (real)1, elK = (real)0;
-            MTRPL_ORDER_SWITCH(order, (nq_predict<K, V>(z), el0 = (real)NqC<K>::el0, inv_t2 = (real)NqC<K>::inv_t2, elK = (real)NqC<K>::elK))
+            nq_predict<5, V>(z);
+            MTRPL_ORDER_SWITCH(order, (el0 = (real)NqC<K>::el0, inv_t2 = (real)NqC<K>::inv_t2, elK = (real)NqC<K>::elK))
             const real c = h * el0;
             const real early_scale = (tune.early_factor > 1.0 && t + h <= early_until) ? early_inv : (real)1;
 #pragma unroll
@@ -517,7 +529,8 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             }
             if (!converged) {
                 n_nfail++;
-                MTRPL_ORDER_SWITCH(order, (nq_retract<K, V>(z), nq_rescale<K, V>(z, (real)0.5)))
+                nq_retract<5, V>(z);
+                nq_rescale<5, V>(z, (real)0.5);
                 h *= (real)0.5;
                 n_equal = 0;
                 have_fac = false;
@@ -530,7 +543,8 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                 n_rej++;
                 since_rej = 0;
                 const real fac = fmax((real)0.2, safety * inv_root(dsm, order + 1));
-                MTRPL_ORDER_SWITCH(order, (nq_retract<K, V>(z), nq_rescale<K, V>(z, fac)))
+                nq_retract<5, V>(z);
+                nq_rescale<5, V>(z, fac);
                 h *= fac;
                 n_equal = 0;
                 have_fac = false;
@@ -545,7 +559,12 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         n_equal++;
         since_rej++;
         t += h;
-        MTRPL_ORDER_SWITCH(order, (nq_correct<K, V>(z, acor)))
+        {
+            real el[6];
+            MTRPL_ORDER_SWITCH(order, (el[0] = (real)NqC<K>::T.el[K][0], el[1] = (real)NqC<K>::T.el[K][1], el[2] = (real)NqC<K>::T.el[K][2],
+                                       el[3] = (real)NqC<K>::T.el[K][3], el[4] = (real)NqC<K>::T.el[K][4], el[5] = (real)NqC<K>::T.el[K][5]))
+            nq_correct_rt<V>(z, acor, el);
+        }
         MTRPL_STAMP(ph_ctl);
         // dense output (Taylor polynomial of the Nordsieck array), forward_solver.py:167
         const real ih = frcp(h);
@@ -554,7 +573,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             if (tq > t * (real)(1.0 + 1e-15)) break;
             real yq[V];
             const real s_ = (tq - t) * ih;
-            MTRPL_ORDER_SWITCH(order, (nq_dense<K, V>(z, s_, yq)))
+            nq_dense<5, V>(z, s_, yq);
             bk.out_sample(io, sig_partial(yq));
             io++;
             tq_next = (io < nt) ? (real)ts[io] : big<real>();
@@ -589,17 +608,20 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             n_equal = order - 2;  // keep h and the factors; test again three steps on
             continue;
         }
-        if (dorder == 1) {
-            // new last row z[q+1] = acor * l_q / (q+1)
-            switch (order) {
-                case 1: for (int v = 0; v < V; ++v) z[2][v] = acor[v] * el_up; break;
-                case 2: for (int v = 0; v < V; ++v) z[3][v] = acor[v] * el_up; break;
-                case 3: for (int v = 0; v < V; ++v) z[4][v] = acor[v] * el_up; break;
-                default: for (int v = 0; v < V; ++v) z[5][v] = acor[v] * el_up; break;
+        if (dorder != 0) {
+            // order up: the new last row is z[q+1] = acor * l_q / (q+1); order down: the last row is dropped,
+            // i.e. zeroed.  Row j = 2..5 is scaled by keep_j and receives add_j * acor (both wave-uniform).
+            const int qn = order + dorder;
+#pragma unroll
+            for (int j = 2; j < 6; ++j) {
+                const real keep = (j <= qn && j <= order) ? (real)1 : (real)0;
+                const real add = (dorder == 1 && j == qn) ? el_up : (real)0;
+#pragma unroll
+                for (int v = 0; v < V; ++v) z[j][v] = keep * z[j][v] + add * acor[v];
             }
+            order = qn;
         }
-        order += dorder;
-        MTRPL_ORDER_SWITCH(order, (nq_rescale<K, V>(z, fac)))
+        nq_rescale<5, V>(z, fac);
         h *= fac;
         n_equal = 0;
         have_fac = false;

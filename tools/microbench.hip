@@ -8,8 +8,8 @@
 #include "../metrotrpl_amd/csrc/backend_pair.hpp"
 using namespace mtrpl;
 
-enum { RHS = 0, APPLY, BUILD, REDUCE2, REDUCE4, PUBLISH, PREDICT, CORRECT, DENSE, NWHAT };
-static const char *kNames[] = {"rhs", "apply", "build", "reduce<2>", "reduce<4>", "publish", "predict(5)", "correct(5)", "dense+out"};
+enum { RHS = 0, APPLY, BUILD, REDUCE2, REDUCE4, PUBLISH, PREDICT, CORRECT, DENSE, STEP, NWHAT };
+static const char *kNames[] = {"rhs", "apply", "build", "reduce<2>", "reduce<4>", "publish", "predict(5)", "correct(5)", "dense+out", "bare step"};
 
 template <class BK, int WHAT>
 __device__ inline void body(BK &bk, double *out, long long *cyc, int iters)
@@ -49,6 +49,36 @@ __device__ inline void body(BK &bk, double *out, long long *cyc, int iters)
             for (int r = 0; r < R; ++r) s += signal_density(bk.p, 0, yq[r], yq[R + r]);
             bk.out_sample(it & 1023, s);
             for (int v = 0; v < V; ++v) z[0][v] += 1e-30;
+        }
+        if (WHAT == STEP) {
+            // one accepted order-5 step with a single Newton iteration and one output sample, no controller:
+            // what the building blocks cost when nothing but data flow connects them
+            const double h = 0.5, el0 = NqC<5>::el0;
+            double isc[V], acor[V], yn[V], b[V], dx[V];
+            nq_predict<5, V>(z);
+            for (int v = 0; v < V; ++v) { isc[v] = ctl_rcp(1e-20 + 3e-9 * fabs(z[0][v])); acor[v] = 0.0; yn[v] = z[0][v]; }
+            bk.publish(yn, zE);
+            bk.rhs(yn, f);
+            for (int v = 0; v < V; ++v) b[v] = h * f[v] - z[1][v] - acor[v];
+            bk.apply(b, dx);
+            double s2[2] = {0.0, 0.0};
+            for (int v = 0; v < V; ++v) {
+                const double wv = el0 * dx[v] * isc[v];
+                s2[0] += wv * wv;
+                acor[v] += dx[v] * 1e-9;
+                yn[v] += el0 * dx[v];
+                const double av = acor[v] * isc[v];
+                s2[1] += av * av;
+            }
+            bk.template reduce<2>(s2, yn, zE);
+            acc += s2[0] + s2[1];
+            nq_correct<5, V>(z, acor);
+            double yq[V];
+            nq_dense<5, V>(z, -0.25, yq);
+            double sp = 0.0;
+            for (int r = 0; r < R; ++r) sp += signal_density(bk.p, 0, yq[r], yq[R + r]);
+            bk.out_sample(it & 1023, sp);
+            for (int k = 1; k < 6; ++k) for (int v = 0; v < V; ++v) z[k][v] *= 0.5;  // keep the history bounded
         }
     }
     bk.out_finish();
@@ -101,7 +131,7 @@ int main(int argc, char **argv)
         res[K][W] = m / nblk / iters;                                                                 \
     }
 #define BOTH(W) RUN(0, W, (bench_wave<W>), 64) RUN(1, W, (bench_pair<W, 3>), 128)
-    BOTH(RHS) BOTH(APPLY) BOTH(BUILD) BOTH(REDUCE2) BOTH(REDUCE4) BOTH(PUBLISH) BOTH(PREDICT) BOTH(CORRECT) BOTH(DENSE)
+    BOTH(RHS) BOTH(APPLY) BOTH(BUILD) BOTH(REDUCE2) BOTH(REDUCE4) BOTH(PUBLISH) BOTH(PREDICT) BOTH(CORRECT) BOTH(DENSE) BOTH(STEP)
     printf("%-12s %12s %12s   (cycles per call, %d workgroups)\n", "block", "wave", "pair<2,3>", nblk);
     for (int w = 0; w < NWHAT; ++w) printf("%-12s %12.0f %12.0f\n", kNames[w], res[0][w], res[1][w]);
     return 0;
