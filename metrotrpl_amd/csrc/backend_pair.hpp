@@ -267,8 +267,11 @@ struct PairBackend {
     }
 
     // ---- factorisation of M = I - c*J(y); h = the step behind c (needed for the edge-64 entry) ----
-    __device__ inline void build(const double (&y)[V], double c, double h)
+    __device__ inline void build(const double (&y_in)[V], double c, double h)
     {
+        double y[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) y[v] = pinned(y_in[v]);  // keep the Jacobian inside the branch it is called from
         hcur = h;
         const double cL = c * p.Lam;
         const double dnx = p.DnT * p.idx, dpx = p.DpT * p.idx;

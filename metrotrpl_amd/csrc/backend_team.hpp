@@ -228,8 +228,11 @@ struct TeamBackend {
     }
 
     // ---- Newton matrix factors ----
-    __device__ inline void build(const real (&y)[V], real c, real)
+    __device__ inline void build(const real (&y_in)[V], real c, real)
     {
+        real y[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) y[v] = pinned(y_in[v]);  // keep the Jacobian inside the branch it is called from
         const real cL = c * p.Lam;
         cd = c * p.idx;
         const real dnx = p.DnT * p.idx, dpx = p.DpT * p.idx;

@@ -123,8 +123,11 @@ struct WaveBackend {
     }
 
     // ---- factorisation of M = I - c*J(yJ) ----
-    __device__ inline void build(const double (&y)[V], double c, double)
+    __device__ inline void build(const double (&y_in)[V], double c, double)
     {
+        double y[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) y[v] = pinned(y_in[v]);  // keep the Jacobian inside the branch it is called from
         M2 Lm[R], Rm[R], A[R], B[R], C[R];
         const double cL = c * p.Lam;
         const double dnx = p.DnT * p.idx, dpx = p.DpT * p.idx;

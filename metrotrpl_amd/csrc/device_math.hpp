@@ -25,6 +25,17 @@ template <class T> using vec2_t = typename Vec2<T>::type;
 // "infinity" that survives a conversion to the working precision
 template <class T> __device__ constexpr T big() { return sizeof(T) == 8 ? (T)1e300 : (T)1e30; }
 
+// Pins a value to the point of the program where this stands: the optimiser may neither hoist the
+// computations that consume the result above it nor sink its producers below it.  No instruction.
+// (Used at the top of the factorisation: it sits behind `if (!have_fac)` inside the Newton loop, its
+// inputs are invariant in that loop, and LICM otherwise evaluates half of the Jacobian -- four fp64
+// reciprocals and a hundred multiplies -- speculatively on EVERY step instead of every eleventh.)
+template <class T> __device__ inline T pinned(T x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // ---- lane exchange -------------------------------------------------------------------------------
 template <class T> __device__ inline T shf(T v, int src) { return __shfl(v, src, 64); }
 
