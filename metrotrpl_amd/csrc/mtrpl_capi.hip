@@ -33,7 +33,7 @@ struct Slab {
 struct mtrpl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    SolveTuning tune{0.1, 3e-9, 3e-10, 3e-11, 0.0, 1e-4, 1e-8, 2000000, 0.03, 8, 4.0, 3.0, 1, 1e-11, 0.5, 16.0, 1.2, 80, 1.2, 1.0, 1.0, 1.0, 10.0, 0.5};
+    SolveTuning tune{0.1, 3e-9, 3e-10, 3e-11, 0.0, 1e-4, 1e-8, 2000000, 0.1, 8, 4.0, 3.0, 1, 1e-11, 0.5, 16.0, 1.2, 80, 1.2, 1.0, 1.0, 1.0, 10.0, 0.5};
     std::string err;
     // IRF tables resident on the device (mtrpl_irf_tables_upload)
     double *d_irf_tab = nullptr;
