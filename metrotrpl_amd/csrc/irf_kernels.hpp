@@ -413,6 +413,39 @@ __device__ inline int conv_run_of(const ConvCtx &c, int64_t j)
     return lo;
 }
 
+// block-wide NaN-propagating maxima of three values (any number of full waves); sv: >= 3*blockDim.x/64 doubles
+// of LDS.  Every thread gets the results.
+__device__ inline double nanmax(double a, double b) { return (b > a || b != b) ? b : a; }
+__device__ inline void block_max3(double &a, double &b, double &c, double *sv)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a = nanmax(a, __shfl_xor(a, o, 64));
+        b = nanmax(b, __shfl_xor(b, o, 64));
+        c = nanmax(c, __shfl_xor(c, o, 64));
+    }
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sv[3 * wave] = a; sv[3 * wave + 1] = b; sv[3 * wave + 2] = c; }
+    __syncthreads();
+    a = sv[0]; b = sv[1]; c = sv[2];
+    for (int w = 1; w < nw; ++w) { a = nanmax(a, sv[3 * w]); b = nanmax(b, sv[3 * w + 1]); c = nanmax(c, sv[3 * w + 2]); }
+    __syncthreads();
+}
+// block-wide sums of three values, same scratch
+__device__ inline void block_sum3(double &a, double &b, double &c, double *sv)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); }
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sv[3 * wave] = a; sv[3 * wave + 1] = b; sv[3 * wave + 2] = c; }
+    __syncthreads();
+    a = sv[0]; b = sv[1]; c = sv[2];
+    for (int w = 1; w < nw; ++w) { a += sv[3 * w]; b += sv[3 * w + 1]; c += sv[3 * w + 2]; }
+    __syncthreads();
+}
+
 // One trace: everything the block needs sits behind the pointers it is given.  `work` holds the
 // per-sample arrays (6*max_nt doubles: times, signal, slopes, compared signal, 2u^2, run table), `irfw` the
 // IRF work space (moment table + its prefix sums); the kernel below decides which of them are LDS.
@@ -477,16 +510,51 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
         for (int q = tid; q < nt - 1; q += kLikeBlock) conv_runs(c, q, jlo[q], jhi[q]);
         __syncthreads();
         // ---- pass A: argmax of the convolved trace (laplace.py:82) ----
+        // The outputs are walked in chunks, and the walk stops as soon as no later output can still win.
+        // Every tap of h[k] is y1*T0 + (y2 - y0)*T1 + 2*(y2 - 2*y1 + y0)*T2 with y0, y1, y2 values of the linear
+        // interpolant half_dt apart at times >= tau(2*(k - nk)).  With Y = max |sy| and S = max |slope| over the
+        // intervals that reach past tau(2*(k0 - nk)):  |y1| <= Y, |y2 - y0| <= 2*half_dt*S,
+        // |2*(y2 - 2*y1 + y0)| <= 4*half_dt*S, so for all k >= k0
+        //     |h[k]| <= Y*sum|T0| + half_dt*S*(2*sum|T1| + 4*sum|T2|),
+        // and once that lies strictly below the maximum found so far, argmax is decided (ties go to the smaller
+        // index anyway).  A TRPL decay peaks in its first nanoseconds: most of the 80 000 outputs of a 2000 ns
+        // trace are never computed.  A NaN sample keeps the bound NaN and the walk complete; a NaN output found
+        // ends it (np.argmax returns the first NaN).
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+        for (int m = tid; m < nk; m += kLikeBlock) { w0 += fabs(T[3 * m]); w1 += fabs(T[3 * m + 1]); w2 += fabs(T[3 * m + 2]); }
+        block_sum3(w0, w1, w2, red_v);
+        const double wy = w0 * (1.0 + 1e-9), ws = half_dt * (2.0 * w1 + 4.0 * w2) * (1.0 + 1e-9);
         double best = 0.0;
         int64_t bi = nkk + 1;
         {
             // outputs interleaved over the threads: neighbouring lanes work on neighbouring k, so their
             // windows share the runs (LDS broadcasts) and their prefix-sum indices are consecutive
             // (conflict-free); the run pointer still only moves forward per thread
+            constexpr int64_t kChunk = 2 * kLikeBlock;
             int qh = conv_run_of(c, (tid - nk > 0) ? tid - nk : 0);
-            for (int64_t k = tid; k <= nkk; k += kLikeBlock) {
-                const double acc = conv_fast2(c, k, qh);
-                if (argmax_better(acc, k, best, bi, nkk + 1)) { best = acc; bi = k; }
+            for (int64_t k0 = 0; k0 <= nkk; k0 += kChunk) {
+                if (k0 > 0) {
+                    const double t_lo = (k0 > nk) ? (double)(2 * (k0 - nk)) * half_dt * (1.0 - 1e-12) : 0.0;
+                    double ymax = 0.0, smax = 0.0;
+                    for (int i = tid; i < nt; i += kLikeBlock) {
+                        if (st[i + 1 < nt ? i + 1 : i] >= t_lo) {
+                            const double a = fabs(sy[i]);
+                            ymax = (a > ymax || a != a) ? a : ymax;
+                            if (i < nt - 1) {
+                                const double b = fabs(sb[i]);
+                                smax = (b > smax || b != b) ? b : smax;
+                            }
+                        }
+                    }
+                    double bmax = (best != best) ? __builtin_inf() : best;  // -> the best value of the whole block so far
+                    block_max3(bmax, ymax, smax, red_v);
+                    if (ymax * wy + smax * ws < bmax) break;                // the same decision in every thread
+                }
+                const int64_t k_end = (k0 + kChunk <= nkk) ? k0 + kChunk : nkk + 1;
+                for (int64_t k = k0 + tid; k < k_end; k += kLikeBlock) {
+                    const double acc = conv_fast2(c, k, qh);
+                    if (argmax_better(acc, k, best, bi, nkk + 1)) { best = acc; bi = k; }
+                }
             }
         }
         block_argmax(best, bi, nkk + 1, red_v, red_i);
@@ -581,14 +649,36 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
     __syncthreads();
     const double sg2 = ds.sigma * ds.sigma;
     if (nT >= 32) {
-        // many ladder temperatures: one thread per temperature walks the n_c points
-        for (int j = tid; j < nT; j += kLikeBlock) {
-            const double sT = sg2 * temps[j];
-            double tot = 0.0;
-            for (int i = 0; i < n_c; ++i) tot += sol[i] * frcp(sT + su2[i]);  // frcp: ~1 ulp, no div ladder
-            tot = -tot;
-            if (failed || tot != tot) tot = -__builtin_inf();  // :70-72,:159-165
-            ll[sidx * nT + j] = tot;
+        // many ladder temperatures: kLadderSplit threads per temperature walk interleaved points, their partial
+        // sums are added in a fixed order (the IRF work space is free by now and holds them)
+        constexpr int kLadderSplit = 8;
+        double *parts = irfw;  // [nT][kLadderSplit] -- when that fits in the 6*nk+3 doubles of the IRF work space
+        const bool fits = ds.irf >= 0 && (size_t)nT * kLadderSplit <= 6 * (size_t)set.nk[ds.irf];
+        if (fits) {
+            for (int u = tid; u < nT * kLadderSplit; u += kLikeBlock) {
+                const int j = u / kLadderSplit, r = u - j * kLadderSplit;
+                const double sT = sg2 * temps[j];
+                double tot = 0.0;
+                for (int i = r; i < n_c; i += kLadderSplit) tot += sol[i] * frcp(sT + su2[i]);  // frcp: ~1 ulp, no div ladder
+                parts[u] = tot;
+            }
+            __syncthreads();
+            for (int j = tid; j < nT; j += kLikeBlock) {
+                double tot = 0.0;
+                for (int r = 0; r < kLadderSplit; ++r) tot += parts[j * kLadderSplit + r];
+                tot = -tot;
+                if (failed || tot != tot) tot = -__builtin_inf();  // :70-72,:159-165
+                ll[sidx * nT + j] = tot;
+            }
+        } else {
+            for (int j = tid; j < nT; j += kLikeBlock) {
+                const double sT = sg2 * temps[j];
+                double tot = 0.0;
+                for (int i = 0; i < n_c; ++i) tot += sol[i] * frcp(sT + su2[i]);
+                tot = -tot;
+                if (failed || tot != tot) tot = -__builtin_inf();
+                ll[sidx * nT + j] = tot;
+            }
         }
     } else {
         for (int j = 0; j < nT; ++j) {
@@ -629,7 +719,7 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
                                                             double *__restrict__ gwork)
 {
     extern __shared__ double smem[];
-    __shared__ double red_v[kLikeWaves];
+    __shared__ double red_v[3 * kLikeWaves];
     __shared__ int64_t red_i[kLikeWaves];
     __shared__ int s_cnt[2];
     double *work = GWORK ? gwork + (size_t)blockIdx.x * 6 * (size_t)max_nt : smem;

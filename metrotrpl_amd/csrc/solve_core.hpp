@@ -214,6 +214,9 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                                  int32_t *__restrict__ status, int32_t *__restrict__ stats, int64_t sidx,
                                  const SolveTuning &tune, unsigned long long clk0_)
 {
+#ifdef MTRPL_SCHED
+    const unsigned long long sched_t0_ = __builtin_amdgcn_s_memrealtime();
+#endif
     using real = typename BK::real;
     constexpr int R = BK::R, V = BK::V;
     constexpr bool TRAPS = BK::TRAPS;
@@ -645,6 +648,12 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             s[0] = n_steps; s[1] = n_rhs; s[2] = n_fac; s[3] = n_jac;
             s[4] = n_rej; s[5] = n_nfail; s[6] = order;
             s[7] = (int32_t)((__builtin_amdgcn_s_memtime() - clk0_) >> 4);  // residency of this solve, 16-tick units
+#ifdef MTRPL_SCHED  // diagnostic build (tools/sched_trace.py): when (100 MHz real-time counter) and where the solve ran
+            s[5] = (int32_t)(sched_t0_ & 0x7fffffff);
+            s[3] = (int32_t)(__builtin_amdgcn_s_memrealtime() & 0x7fffffff);
+            s[6] = (int32_t)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID, 32 bits
+            s[4] = (int32_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // XCC_ID
+#endif
 #ifdef MTRPL_STAMPS
             s[1] = (int)(ph_ctl >> 10); s[2] = (int)(ph_fac >> 10); s[3] = (int)(ph_rhs >> 10);
             s[4] = (int)(ph_app >> 10); s[5] = (int)(ph_red >> 10); s[6] = (int)(ph_glue >> 10);

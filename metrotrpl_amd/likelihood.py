@@ -77,6 +77,8 @@ class LikelihoodEngine:
         self.split_min, self.sort_min = int(split_min), int(sort_min)
         self._side = []
         self._cap = 0
+        self._tmpl = {}
+        self._ticks = None
         self.timing = None  # a list: launch() appends (stream, e0, e1, e2, n_solves) HIP-event triples around
         #                     the solve and the likelihood kernel of every block (bench.py: roofline)
 
@@ -90,29 +92,19 @@ class LikelihoodEngine:
             self.d_stats = torch.zeros(n_solves * 8, dtype=torch.int32, device=self.dev)
         self.d_ll = torch.zeros(n_solves * nT, dtype=torch.float64, device=self.dev)
 
-    def descriptors(self, states):
-        """Host-side packing for C chains x M measurements (chain-major)."""
-        states = np.atleast_2d(np.asarray(states, dtype=np.float64))
-        Cn = states.shape[0]
-        st = np.repeat(states, self.M, axis=0)
+    def _template(self, Cn):
+        """Everything in the descriptors of C chains x M measurements (chain-major) that does not depend on the
+        states: grids, offsets, tolerances, measurement kinds, validation -- built once per ensemble size."""
+        tm = self._tmpl.get(Cn)
+        if tm is not None:
+            return tm
         ini = np.tile(self.iniPar, (Cn, 1))
-        shift = np.tile(self.scale_shift, Cn)
-        rows = np.repeat(np.arange(Cn), self.M)
-        for key, col in (("fluences", 0), ("absps", 1)):
-            idx = np.tile(self.fit[key], Cn)
-            use = idx >= 0
-            if use.any():  # a COPY of the init row is scaled (the reference compounds in place, :44/:51)
-                ini[use, col] *= states[rows[use], idx[use]]
-        idx = np.tile(self.fit["scale"], Cn)
-        use = idx >= 0
-        if use.any():
-            with np.errstate(divide="ignore", invalid="ignore"):
-                shift[use] = np.log10(states[rows[use], idx[use]])
         thick = np.tile(self.lengths, Cn)
         meas = self.meas_types * Cn
         per_chain = int(np.sum(self.nts))
         out_off = (np.repeat(np.arange(Cn, dtype=np.int64), self.M) * per_chain + np.tile(self.t_off, Cn))
-        d, ini_arr = batch.build_batch(st, self.indexes, self.units, ini, thick, self.nx, 1, hmax=self.hmax, meas=meas,
+        dummy = np.ones((Cn * self.M, self.units.shape[0]))
+        d, ini_arr = batch.build_batch(dummy, self.indexes, self.units, ini, thick, self.nx, 1, hmax=self.hmax, meas=meas,
                                        model=self.model, ini_mode=self.ini_mode, RTOL=self.rtol, ATOL=self.atol)
         d["nx"] = np.tile(self.nx_list, Cn)
         d["nt"] = np.tile(self.nts, Cn)
@@ -126,8 +118,36 @@ class LikelihoodEngine:
         ld["n_exp"] = d["nt"]
         ld["irf"] = np.tile(self.irf_index, Cn)
         ld["force_min_y"] = int(self.force_min_y)
-        ld["scale_shift"] = shift
+        ld["scale_shift"] = np.tile(self.scale_shift, Cn)
         ld["sigma"] = np.tile(self.sigma, Cn)
+        rows = np.repeat(np.arange(Cn), self.M)
+        fit = {}
+        for key in ("fluences", "absps", "scale"):
+            idx = np.tile(self.fit[key], Cn)
+            use = idx >= 0
+            fit[key] = (use, rows[use], idx[use]) if use.any() else None
+        tm = self._tmpl[Cn] = dict(d=d, ini_arr=ini_arr, ld=ld, ini3=d["ini"].copy(), fit=fit)
+        return tm
+
+    def descriptors(self, states):
+        """Host-side packing for C chains x M measurements (chain-major)."""
+        states = np.atleast_2d(np.asarray(states, dtype=np.float64))
+        Cn = states.shape[0]
+        tm = self._template(Cn)
+        d, ld, ini_arr, fit = tm["d"].copy(), tm["ld"], tm["ini_arr"], tm["fit"]
+        d["par"] = np.repeat(batch.pack_params(states * self.units, self.indexes), self.M, axis=0)
+        if fit["fluences"] is not None or fit["absps"] is not None:
+            ini3 = tm["ini3"].copy()  # a COPY of the init row is scaled (the reference compounds in place, :44/:51)
+            for key, col in (("fluences", 0), ("absps", 1)):
+                if fit[key] is not None:
+                    use, r, i = fit[key]
+                    ini3[use, col] *= states[r, i]
+            d["ini"] = ini3
+        if fit["scale"] is not None:
+            use, r, i = fit["scale"]
+            ld = ld.copy()
+            with np.errstate(divide="ignore", invalid="ignore"):
+                ld["scale_shift"][use] = np.log10(states[r, i])
         # Over-subscribed launches (more solves than SIMDs) are cut into `parts` chain blocks that
         # run on separate HIP streams: the likelihood kernel of one block overlaps the solve tail of
         # the next.  Inside a block the expensive solves go first (the hardware hands out workgroups
@@ -140,9 +160,10 @@ class LikelihoodEngine:
         self._order = None
         if self.sort_by_cost and n > self.sort_min:
             cost = self._measured_cost(n, states)
+            self._cost_kind = "measured" if cost is not None else "heuristic"
             if cost is None:  # first launch: the tightened-tolerance solves (tauP >> tauN) are the slow ones
-                tn, tp = st[:, self.indexes["tauN"]], st[:, self.indexes["tauP"]]
-                cost = 1.0 + tp / tn
+                tn, tp = states[:, self.indexes["tauN"]], states[:, self.indexes["tauP"]]
+                cost = np.repeat(1.0 + tp / tn, self.M)
             order = np.concatenate([a + np.argsort(-cost[a:b], kind="stable") for a, b in zip(cuts[:-1], cuts[1:])])
             d = d[order]
             self._order = order
@@ -151,8 +172,10 @@ class LikelihoodEngine:
 
     def _measured_cost(self, n, states):
         """Residency of every solve in the previous launch (stats[7]), in chain-major order: Metropolis
-        proposals are small moves, so the last iteration's cost is the best predictor of this one's.
-        Not used when the states are not a small move away from the previous ones (dense sampling)."""
+        proposals are small moves, so the last iteration's cost is the best predictor of this one's.  A
+        replica exchange moves states along the ladder, so each row takes the cost of the closest of the
+        previous rows (within two slots of it, else anywhere).  Not used when some state has no previous state nearby
+        (dense sampling)."""
         prev = getattr(self, "_prev_order", None)
         last = getattr(self, "_prev_states", None)
         self._prev_states = np.array(states, dtype=np.float64, copy=True)
@@ -160,24 +183,49 @@ class LikelihoodEngine:
             return None
         if last is None or last.shape != self._prev_states.shape:
             return None
+        Cn = states.shape[0]
         with np.errstate(all="ignore"):
-            ratio = np.abs(np.log(np.abs(self._prev_states) / np.abs(last)))
-        if not np.all(np.nan_to_num(ratio, nan=0.0) < 2.0):
+            cur, old = np.log(np.abs(self._prev_states)), np.log(np.abs(last))
+            best, src = np.full(Cn, np.inf), np.arange(Cn)
+            for o in (0, 1, -1, 2, -2):
+                dist = np.nan_to_num(np.abs(cur - np.roll(old, -o, axis=0)), nan=0.0, posinf=np.inf).max(axis=1)
+                upd = dist < best
+                best[upd] = dist[upd]
+                src[upd] = (np.arange(Cn)[upd] + o) % Cn
+            far = best >= 2.0
+            if far.any() and int(far.sum()) * Cn <= 200000:  # moved further than two slots: look everywhere
+                dall = np.nan_to_num(np.abs(cur[far][:, None, :] - old[None, :, :]), nan=0.0, posinf=np.inf).max(axis=2)
+                j = dall.argmin(axis=1)
+                best[far], src[far] = dall[np.arange(j.shape[0]), j], j
+        if not np.all(best < 2.0):
             return None
-        ticks = self.d_stats[:8 * n].view(-1, 8)[:, 7].cpu().numpy().astype(np.float64)
+        if self._ticks is not None and self._ticks[1] == n:  # copied back right behind the launch
+            self._ticks[2].synchronize()
+            ticks = self._ticks[0][:n].numpy().astype(np.float64)
+        else:
+            ticks = self.d_stats[:8 * n].view(-1, 8)[:, 7].cpu().numpy().astype(np.float64)
         if not np.any(ticks > 0):
             return None
         cost = np.empty(n)
         cost[prev] = ticks
-        return cost
+        return cost.reshape(Cn, self.M)[src].reshape(-1)
+
+    def _const(self, tm, key, arr):
+        """Device copy of a descriptor array; the template's own (state-independent) arrays go up once."""
+        raw = arr.view(np.uint8).reshape(-1) if arr.dtype.names else arr
+        if arr is not tm[key]:
+            return self.torch.from_numpy(raw).to(self.dev)
+        if "dev_" + key not in tm:
+            tm["dev_" + key] = self.torch.from_numpy(raw).to(self.dev)
+        return tm["dev_" + key]
 
     def upload(self, states):
-        torch = self.torch
         d, ini_arr, ld = self.descriptors(states)
         self.n_solves = d.shape[0]
-        self.d_descs = torch.from_numpy(d.view(np.uint8).reshape(-1)).to(self.dev)
-        self.d_ini = torch.from_numpy(ini_arr).to(self.dev)
-        self.d_like = torch.from_numpy(ld.view(np.uint8).reshape(-1)).to(self.dev)
+        tm = self._template(self.n_solves // self.M)
+        self.d_descs = self.torch.from_numpy(d.view(np.uint8).reshape(-1)).to(self.dev)
+        self.d_ini = self._const(tm, "ini_arr", ini_arr)
+        self.d_like = self._const(tm, "ld", ld)
 
     def launch(self, d_T, nT, stream=None):
         """Enqueue solve + likelihood for the uploaded states on `stream` (torch stream); with
@@ -227,6 +275,17 @@ class LikelihoodEngine:
         for ev in joins:
             main.wait_event(ev)
         self._prev_order = self._order  # which solve sat where, for the cost read-back of the next launch
+        if self._order is not None:
+            # the residencies of this launch, for the ordering of the next: copied to pinned memory behind the
+            # kernels instead of a blocking read when the next launch is being packed
+            n = self.n_solves
+            if self._ticks is None or self._ticks[0].shape[0] < n:
+                self._ticks = [torch.empty(n, dtype=torch.int32, pin_memory=True), 0, torch.cuda.Event()]
+            self._ticks[0][:n].copy_(self.d_stats[:8 * n].view(-1, 8)[:, 7], non_blocking=True)
+            self._ticks[1] = n
+            self._ticks[2].record(main)
+        else:
+            self._ticks = None
         return self.d_ll
 
     def eval(self, states, temperatures=(1.0,)):

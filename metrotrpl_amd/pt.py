@@ -38,49 +38,72 @@ def partition(n_chains, world):
     return out
 
 
+class Proposer:
+    """make_trial_move (trial_move_generation.py:51-96) + approve_move (:4-49) for every chain at once,
+    with the per-parameter tables laid out once: uniform box of half-width sqrt(T)*base_move
+    (metropolis.py:43-44) in (log-)space, re-drawn up to MAX_PROPOSALS times for the chains whose proposal
+    fails the checks.  Chain c only ever sees row c of each round's draw, so its proposal does not depend on
+    the other chains."""
+
+    def __init__(self, base_move, names, active, prior, do_log, ix, hard_bounds=True):
+        self.do_log = np.asarray(do_log, dtype=bool)
+        self.all_log = bool(self.do_log.all())
+        self.base = np.asarray(base_move, dtype=np.float64)
+        self.active = np.asarray(active, dtype=bool)
+        self.lo = np.array([prior[p][0] if self.active[i] else -np.inf for i, p in enumerate(names)], dtype=np.float64)
+        self.hi = np.array([prior[p][1] if self.active[i] else np.inf for i, p in enumerate(names)], dtype=np.float64)
+        self.skip = ~self.active
+        self.pn = (ix["p0"], ix["n0"]) if "p0" in ix and "n0" in ix else None
+        self.tau = (ix["tauN"], ix["tauP"]) if "tauN" in ix and "tauP" in ix else None
+        self.rounds = MAX_PROPOSALS if hard_bounds else 1
+
+    def to_lin(self, x):
+        return 10.0 ** x if self.all_log else np.where(self.do_log, 10.0 ** x, x)
+
+    def approve(self, new_log):
+        """True = all checks of approve_move pass; new_log: [C, n] in proposal space (log10 where do_log)."""
+        lin = self.to_lin(new_log)
+        ok = (((self.lo < lin) & (lin < self.hi)) | self.skip).all(axis=1)
+        if self.pn is not None:
+            ok &= new_log[:, self.pn[0]] > new_log[:, self.pn[1]]
+        if self.tau is not None:
+            tn, tp = self.tau
+            ltn = new_log[:, tn] if self.do_log[tn] else np.log10(new_log[:, tn])
+            ltp = new_log[:, tp] if self.do_log[tp] else np.log10(new_log[:, tp])
+            ok &= np.abs(ltn - ltp) <= 2
+        return ok
+
+    def __call__(self, states, temperatures, rng):
+        cur = np.log10(states) if self.all_log else np.where(self.do_log, np.log10(np.where(self.do_log, states, 1.0)), states)
+        width = np.sqrt(np.asarray(temperatures))[:, None] * self.base[None, :]
+        new = cur.copy()
+        todo = np.ones(states.shape[0], dtype=bool)
+        for _ in range(self.rounds):
+            u = rng.random(states.shape)
+            cand = cur + width * (2 * u - 1)
+            new[todo] = cand[todo]
+            todo &= ~self.approve(new)
+            if not todo.any():
+                break
+        return self.to_lin(new)
+
+
 def approve(new_state_log, names, active, prior, do_log, ix):
-    """trial_move_generation.py:4-49, vectorised over chains; True = all checks pass.
-    new_state_log: [C, n] in proposal space (log10 where do_log)."""
-    lin = np.where(do_log, 10.0 ** new_state_log, new_state_log)
-    ok = np.ones(new_state_log.shape[0], dtype=bool)
-    for i, p in enumerate(names):
-        if not active[i]:
-            continue
-        lo, hi = prior[p]
-        ok &= (lo < lin[:, i]) & (lin[:, i] < hi)
-    if "p0" in ix and "n0" in ix:
-        ok &= new_state_log[:, ix["p0"]] > new_state_log[:, ix["n0"]]
-    if "tauN" in ix and "tauP" in ix:
-        ltn = new_state_log[:, ix["tauN"]] if do_log[ix["tauN"]] else np.log10(new_state_log[:, ix["tauN"]])
-        ltp = new_state_log[:, ix["tauP"]] if do_log[ix["tauP"]] else np.log10(new_state_log[:, ix["tauP"]])
-        ok &= np.abs(ltn - ltp) <= 2
-    return ok
+    """trial_move_generation.py:4-49, vectorised over chains; True = all checks pass."""
+    return Proposer(np.zeros(len(names)), names, active, prior, do_log, ix).approve(np.asarray(new_state_log))
 
 
 def propose(states, temperatures, base_move, names, active, prior, do_log, ix, rng, hard_bounds=True):
-    """make_trial_move (trial_move_generation.py:51-96) for every chain at once:
-    uniform box of half-width sqrt(T)*base_move (metropolis.py:43-44) in (log-)space,
-    re-drawn up to MAX_PROPOSALS times for chains whose proposal fails approve_move."""
-    do_log = np.asarray(do_log, dtype=bool)
-    cur = np.where(do_log, np.log10(np.where(do_log, states, 1.0)), states)
-    width = np.sqrt(np.asarray(temperatures))[:, None] * np.asarray(base_move)[None, :]
-    new = cur.copy()
-    todo = np.ones(states.shape[0], dtype=bool)
-    for _ in range(MAX_PROPOSALS if hard_bounds else 1):
-        u = rng.random(states.shape)
-        cand = cur + width * (2 * u - 1)
-        new[todo] = cand[todo]
-        todo &= ~approve(new, names, active, prior, do_log, ix)
-        if not todo.any():
-            break
-    return np.where(do_log, 10.0 ** new, new)
+    """One-off form of `Proposer` (builds the tables on every call)."""
+    return Proposer(base_move, names, active, prior, do_log, ix, hard_bounds)(states, temperatures, rng)
 
 
-def metropolis_accept(logll_cur, logll_new, rng):
-    """metropolis.py:48-53: accept if u < exp(logll_new - logll_cur); NaN -> reject."""
+def metropolis_accept(logll_cur, logll_new, rng, rows=None):
+    """metropolis.py:48-53: accept if u < exp(logll_new - logll_cur); NaN -> reject.
+    rows = (n, sel): the chains are rows `sel` of an n-chain ensemble whose accept roll is drawn whole."""
     lr = logll_new - logll_cur
     lr = np.where(np.isnan(lr), -np.inf, lr)
-    u = rng.random(lr.shape[0])
+    u = rng.random(lr.shape[0]) if rows is None else rng.random(rows[0])[rows[1]]
     with np.errstate(over="ignore"):
         return u < np.exp(lr)
 
@@ -110,73 +133,278 @@ def replica_exchange(table, rng):
     return owner, attempts, accepts
 
 
+class TableGather:
+    """One evaluator call on this rank's block of every state array in `states_list` (each [n_chains,
+    n_params]) at all ladder temperatures, and ONE all-gather of the results (RCCL on GPUs, gloo in the CPU
+    tests).  Construction only enqueues (on `stream` when given): the evaluator's kernels, the collective and
+    the copy to pinned host memory; `tables()` waits and returns the list of [n_chains, nT] numpy arrays."""
+
+    def __init__(self, evaluator, states_list, temperatures, blocks, rank=0, world=1, group=None, stream=None):
+        import torch
+        import torch.distributed as dist
+        lo, hi = blocks[rank]
+        self.c, self.G, self.world = hi - lo, len(states_list), world
+        self.sizes = [b[1] - b[0] for b in blocks]
+        mx = max(self.sizes)
+        block = states_list[0][lo:hi] if self.G == 1 else np.concatenate([s[lo:hi] for s in states_list], axis=0)
+        self.event = None
+        with (torch.cuda.stream(stream) if stream is not None else _Nothing()):
+            local = evaluator(block, temperatures)
+            self.nT = local.shape[1]
+            self.single = world == 1 and not (dist.is_available() and dist.is_initialized())
+            if self.single:
+                dev_result = local
+            else:
+                if len(set(self.sizes)) == 1:
+                    send = local.contiguous()
+                else:
+                    # uneven blocks: collectives want equal shapes, so every group is padded to the largest block
+                    send = torch.zeros((self.G, mx, self.nT), dtype=local.dtype, device=local.device)
+                    send[:, :self.c] = local.view(self.G, self.c, self.nT)
+                    send = send.view(self.G * mx, self.nT)
+                dev_result = torch.empty((world * self.G * mx, self.nT), dtype=local.dtype, device=local.device)
+                dist.all_gather_into_tensor(dev_result, send, group=group)
+            if dev_result.is_cuda and stream is not None:
+                self.pool_key = (tuple(dev_result.shape), dev_result.dtype)
+                free = _PINNED.setdefault(self.pool_key, [])
+                self.host = free.pop() if free else torch.empty(dev_result.shape, dtype=dev_result.dtype, pin_memory=True)
+                self.host.copy_(dev_result, non_blocking=True)
+                self.event = torch.cuda.Event()
+                self.event.record(stream)
+                self.keep = dev_result  # alive until the copy has run
+            else:
+                self.host = dev_result.detach().cpu()
+
+    def tables(self):
+        if self.event is not None:
+            self.event.synchronize()
+            self.keep = None
+            arr = self.host.numpy().copy()
+            _PINNED[self.pool_key].append(self.host)  # the pinned buffer goes back for the next launch
+        else:
+            arr = self.host.numpy()
+        if self.single:
+            return [arr[g * self.c:(g + 1) * self.c] for g in range(self.G)]
+        mx = max(self.sizes)
+        arr = arr.reshape(self.world, self.G, mx, self.nT)
+        return [np.concatenate([arr[r, g, :self.sizes[r]] for r in range(self.world)], axis=0) for g in range(self.G)]
+
+
+_PINNED = {}  # (shape, dtype) -> idle pinned host buffers of TableGather
+
+
+class _Nothing:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def gather_ll_tables(evaluator, states_list, temperatures, blocks, rank=0, world=1, group=None):
+    """Several state arrays through one evaluator call and one collective -> list of [n_chains, nT] tables."""
+    return TableGather(evaluator, states_list, temperatures, blocks, rank, world, group).tables()
+
+
 def gather_ll_table(evaluator, states, temperatures, blocks, rank=0, world=1, group=None):
-    """Evaluate this rank's block of chain states at all ladder temperatures and
-    all-gather the [n_chains, nT] table (one collective; RCCL on GPUs, gloo in CPU tests)."""
-    import torch
-    import torch.distributed as dist
-    lo, hi = blocks[rank]
-    n = blocks[-1][1]
-    local = evaluator(states[lo:hi], temperatures)
-    if world == 1 and not (dist.is_available() and dist.is_initialized()):
-        return local.detach().cpu().numpy()
-    sizes = [b[1] - b[0] for b in blocks]
-    if len(set(sizes)) == 1:
-        full = torch.empty((n, local.shape[1]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(full, local.contiguous(), group=group)
-    else:
-        # uneven blocks: collectives want equal shapes, so pad to the largest block
-        mx = max(sizes)
-        padded = torch.zeros((mx, local.shape[1]), dtype=local.dtype, device=local.device)
-        padded[:local.shape[0]] = local
-        buf = torch.empty((world * mx, local.shape[1]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(buf, padded, group=group)
-        full = torch.cat([buf[r * mx:r * mx + s] for r, s in enumerate(sizes)], dim=0)
-    return full.cpu().numpy()
+    """One state array -> its [n_chains, nT] table (see TableGather)."""
+    return gather_ll_tables(evaluator, [states], temperatures, blocks, rank, world, group)[0]
+
+
+PROPOSE, ACCEPT, SWAP = 0, 1, 2  # what a counter-mode draw is for
+
+
+class _Rows:
+    """Rows `sel` of the [n, ...] uniforms a whole-ensemble draw would produce (proposals of a chain group)."""
+
+    def __init__(self, rng, n, sel):
+        self.rng, self.n, self.sel = rng, n, sel
+
+    def random(self, shape):
+        return self.rng.random((self.n,) + tuple(shape[1:]))[self.sel]
 
 
 class PTEnsemble:
     """One rank's view of the sharded ensemble.
 
-    evaluator(states_block [c, n_params], temperatures [nT]) -> torch tensor
-    [c, nT] (sum over measurements) on the device the process group works on."""
+    evaluator(states_block [c, n_params], temperatures [nT]) -> torch tensor [c, nT] (sum over
+    measurements) on the device the process group works on; or a LIST of such evaluators, one per chain
+    group (below).
 
-    def __init__(self, states, temperatures, evaluator, rank=0, world=1, seed=235817049752375780, group=None):
+    rng_mode "stream": every draw comes from one shared-seed generator in program order, like the
+    reference's walk (metropolis.py:296).  rng_mode "counter": the draws of iteration k for purpose w
+    (proposal / accept roll / swaps) come from a Philox generator keyed by (seed, k, w) -- they do not
+    depend on how many numbers earlier iterations consumed.  That buys two things, both walking exactly the
+    chain the one-iteration-at-a-time run walks:
+      * prefetching: the proposals of iteration k+1 for BOTH outcomes of iteration k are evaluated in the
+        same launch as iteration k's (a GPU with idle SIMDs does two iterations in one solve latency);
+      * chain groups: between two replica exchanges the chains do not interact, so the ensemble is cut into
+        `groups` interleaved sets (chain c in group c % groups), each with its own evaluator and HIP stream;
+        while the host decides and re-proposes for one group, the other group's launch is on the GPU."""
+
+    def __init__(self, states, temperatures, evaluator, rank=0, world=1, seed=235817049752375780, group=None,
+                 rng_mode="stream", streams=None):
+        if rng_mode not in ("stream", "counter"):
+            raise ValueError("rng_mode must be 'stream' or 'counter'")
         self.states = np.array(states, dtype=np.float64)
         self.T = np.asarray(temperatures, dtype=np.float64)
         self.n = self.states.shape[0]
         self.rank, self.world, self.group = rank, world, group
         self.blocks = partition(self.n, world)
         self.lo, self.hi = self.blocks[rank]
-        self.evaluator = evaluator
+        self.evaluators = list(evaluator) if isinstance(evaluator, (list, tuple)) else [evaluator]
+        self.groups = len(self.evaluators)
+        if self.groups > 1 and rng_mode != "counter":
+            raise ValueError("chain groups need rng_mode='counter'")
+        self.streams = list(streams) if streams is not None else [None] * self.groups
+        # group g = chains g, g + groups, ...; gblocks[g][r] = rank r's rows of the group's state array
+        self.sel = [np.arange(g, self.n, self.groups) for g in range(self.groups)]
+        self.gblocks = [[(int(np.searchsorted(sel, lo)), int(np.searchsorted(sel, hi))) for lo, hi in self.blocks]
+                        for sel in self.sel]
+        self.rng_mode = rng_mode
+        self.seed = int(seed)
         self.rng = np.random.default_rng(seed)  # metropolis.py:296 (same seed on every rank, :410-411)
+        self._philox = None
+        self.it = 0  # iterations done (by every group)
+        self.git = [0] * self.groups
+        self.pending = {}
         self.table = None
         self.logll = None
         self.swap_attempts = np.zeros(self.n, dtype=np.int64)
         self.swap_accepts = np.zeros(self.n, dtype=np.int64)
 
+    @property
+    def evaluator(self):
+        return self.evaluators[0]
+
+    @evaluator.setter
+    def evaluator(self, ev):
+        self.evaluators[0] = ev
+
+    def draws(self, it, what):
+        """The generator the draws of iteration `it` for purpose `what` come from."""
+        if self.rng_mode == "stream":
+            return self.rng
+        # ONE generator object, re-keyed in place (an order of magnitude cheaper than building a Philox per
+        # draw): whoever asks uses it up before the next call of draws()
+        if self._philox is None:
+            key = [self.seed & (2 ** 64 - 1), (self.seed >> 64) & (2 ** 64 - 1)]
+            bg = np.random.Philox(key=key, counter=[0, 0, 0, 0])
+            self._philox = (bg, np.random.Generator(bg), bg.state)
+        bg, gen, st = self._philox
+        st["state"]["counter"][:] = [0, 0, what, it]
+        st["buffer"][:] = 0
+        st["buffer_pos"], st["has_uint32"], st["uinteger"] = 4, 0, 0
+        bg.state = st
+        return gen
+
     def gather_table(self, states):
         """Evaluate the local block at all ladder temperatures, all-gather -> [n, nT] numpy."""
-        return gather_ll_table(self.evaluator, states, self.T, self.blocks, self.rank, self.world, self.group)
+        return gather_ll_table(self.evaluators[0], states, self.T, self.blocks, self.rank, self.world, self.group)
 
     def initialise(self):
         self.table = self.gather_table(self.states)
         self.logll = self.table[np.arange(self.n), np.arange(self.n)].copy()
 
+    # ---- one group, one launch: propose + enqueue, then decide --------------------------------------
+    def _begin(self, proposer, g, depth):
+        """Propose the next `depth` (1 or 2) iterations of group g and enqueue their evaluation: per chain
+        the proposal of iteration it+1 and, for depth 2, the two proposals it+2 can make -- from the current
+        state if it+1 rejects, from the it+1 proposal if it accepts."""
+        sel, it = self.sel[g], self.git[g]
+        xs, Ts = self.states[sel], self.T[sel]
+        whole = self.groups == 1
+
+        def rows(i):
+            rng = self.draws(i, PROPOSE)
+            return rng if whole else _Rows(rng, self.n, sel)
+        y1 = proposer(xs, Ts, rows(it + 1))
+        props = [y1]
+        if depth == 2:
+            if self.rng_mode != "counter":
+                raise RuntimeError("prefetching needs rng_mode='counter'")
+            props += [proposer(xs, Ts, rows(it + 2)), proposer(y1, Ts, rows(it + 2))]
+        gather = TableGather(self.evaluators[g], props, self.T, self.gblocks[g], self.rank, self.world, self.group,
+                             self.streams[g])
+        self.pending[g] = (depth, props, gather)
+
+    def _displace(self, g, it, new_states, new_table):
+        """Accept/reject of iteration `it` for group g (metropolis.py:48-63) given the evaluated proposals."""
+        sel = self.sel[g]
+        new_ll = new_table[np.arange(sel.shape[0]), sel]  # chain c sits at ladder slot c
+        rows = None if self.groups == 1 else (self.n, sel)
+        acc = metropolis_accept(self.logll[sel], new_ll, self.draws(it, ACCEPT), rows)
+        idx = sel[acc]
+        self.states[idx] = new_states[acc]
+        self.table[idx] = new_table[acc]
+        self.logll[idx] = new_ll[acc]
+        return acc
+
+    def _end(self, g):
+        depth, props, gather = self.pending.pop(g)
+        tabs = gather.tables()
+        it = self.git[g]
+        accs = [self._displace(g, it + 1, props[0], tabs[0])]
+        if depth == 2:
+            a = accs[0][:, None]
+            accs.append(self._displace(g, it + 2, np.where(a, props[2], props[1]), np.where(a, tabs[2], tabs[1])))
+        self.git[g] = it + depth
+        return accs
+
+    def _exchange(self, it):
+        owner, att, accs = replica_exchange(self.table, self.draws(it, SWAP))
+        self.states = self.states[owner]
+        self.table = self.table[owner]
+        self.logll = self.table[np.arange(self.n), np.arange(self.n)].copy()
+        self.swap_attempts += att
+        self.swap_accepts += accs
+
+    def _all_groups(self, proposer, depth, do_swap):
+        for g in range(self.groups):
+            self._begin(proposer, g, depth)
+        accs = [self._end(g) for g in range(self.groups)]
+        self.it += depth
+        if do_swap:
+            self._exchange(self.it)
+        out = []
+        for d in range(depth):  # back to chain order
+            acc = np.zeros(self.n, dtype=bool)
+            for g in range(self.groups):
+                acc[self.sel[g]] = accs[g][d]
+            out.append(acc)
+        return out
+
     def iterate(self, proposer, do_swap):
         """One Metropolis iteration for every chain (+ replica exchange if do_swap)."""
-        new_states = proposer(self.states, self.T, self.rng)
-        new_table = self.gather_table(new_states)
-        new_ll = new_table[np.arange(self.n), np.arange(self.n)]
-        acc = metropolis_accept(self.logll, new_ll, self.rng)
-        self.states[acc] = new_states[acc]
-        self.table[acc] = new_table[acc]
-        self.logll[acc] = new_ll[acc]
-        if do_swap:
-            owner, att, accs = replica_exchange(self.table, self.rng)
-            self.states = self.states[owner]
-            self.table = self.table[owner]
-            self.logll = self.table[np.arange(self.n), np.arange(self.n)].copy()
-            self.swap_attempts += att
-            self.swap_accepts += accs
-        return acc
+        return self._all_groups(proposer, 1, do_swap)[0]
+
+    def iterate2(self, proposer, do_swap):
+        """Two iterations from ONE evaluator launch and ONE collective per group (no replica exchange between
+        them; `do_swap`: exchange after the second); one of the two speculative evaluations per chain is
+        discarded.  Same chain as two `iterate` calls (counter mode only)."""
+        if self.rng_mode != "counter":
+            raise RuntimeError("iterate2 needs rng_mode='counter'")
+        return tuple(self._all_groups(proposer, 2, do_swap))
+
+    def advance(self, proposer, n_iters, temper_freq, prefetch=False):
+        """`n_iters` iterations with a replica exchange after every `temper_freq`-th (metropolis.py:129).
+        Between two exchanges every chain group runs at its own pace: with `prefetch` two iterations per
+        launch, and with several groups the launch of one overlaps the host work of the others.
+        -> accepted moves."""
+        n_acc, stop = 0, self.it + n_iters
+        while self.it < stop:
+            seg_end = min(stop, (self.it // temper_freq + 1) * temper_freq)  # next exchange or the end
+            depth = lambda g: 2 if prefetch and seg_end - self.git[g] >= 2 else 1  # noqa: E731
+            queue = [g for g in range(self.groups) if self.git[g] < seg_end]
+            for g in queue:
+                self._begin(proposer, g, depth(g))
+            while queue:
+                g = queue.pop(0)
+                n_acc += sum(int(a.sum()) for a in self._end(g))
+                if self.git[g] < seg_end:
+                    self._begin(proposer, g, depth(g))
+                    queue.append(g)
+            self.it = seg_end
+            if seg_end % temper_freq == 0:
+                self._exchange(seg_end)
+        return n_acc

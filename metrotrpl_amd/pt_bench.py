@@ -49,25 +49,32 @@ def synthetic_data(irf_tables, nx, times):
 
 
 def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=True, split_min=2048, sort_min=1024,
-          ctx=None, force_min_y=False):
-    """The config-3/4 problem on one rank: engine, ladder, evaluator and proposer."""
+          ctx=None, force_min_y=False, groups=1):
+    """The config-3/4 problem on one rank: engine(s), ladder, evaluator(s) and proposer.  groups > 1: one
+    engine, evaluator and HIP stream per chain group of pt.PTEnsemble."""
     import torch
     times = W.default_times()
     ctx = ctx or L.default_context(local)
     irf_tables = laplace.make_I_tables({745: synthetic_irf() if irf_raw is None else irf_raw})
     vals, uncs = synthetic_data(irf_tables, nx, times)
-    eng = LikelihoodEngine(W.indexes(), W.units(), W.STAUB_LENGTHS, nx, ["TRPL"] * 6, [times] * 6, vals, uncs,
-                           {"TRPL": 1.0}, np.array(W.STAUB_FLUENCES), ini_mode="fluence", irf_tables=irf_tables,
-                           irf_convolution=[745] * 6, device=local, ctx=ctx, sort_by_cost=sort_by_cost, parts=parts,
-                           split_min=split_min, sort_min=sort_min, force_min_y=force_min_y)
     ens0 = W.pt_ensemble(n_chains, nx)
     T = ens0["temperatures"]
     d_T = torch.from_numpy(np.ascontiguousarray(T)).to(dev)
 
-    def evaluator(states_block, temps):
-        eng.upload(states_block)
-        ll = eng.launch(d_T, len(temps))
-        return ll.view(-1, eng.M, len(temps)).sum(dim=1)
+    def make(_):
+        eng = LikelihoodEngine(W.indexes(), W.units(), W.STAUB_LENGTHS, nx, ["TRPL"] * 6, [times] * 6, vals, uncs,
+                               {"TRPL": 1.0}, np.array(W.STAUB_FLUENCES), ini_mode="fluence", irf_tables=irf_tables,
+                               irf_convolution=[745] * 6, device=local, ctx=ctx, sort_by_cost=sort_by_cost, parts=parts,
+                               split_min=split_min, sort_min=sort_min, force_min_y=force_min_y)
+
+        def evaluator(states_block, temps):
+            eng.upload(states_block)
+            ll = eng.launch(d_T, len(temps))
+            return ll.view(-1, eng.M, len(temps)).sum(dim=1)
+        return eng, evaluator
+    made = [make(g) for g in range(max(1, groups))]
+    engines, evaluators = [m[0] for m in made], [m[1] for m in made]
+    streams = [torch.cuda.Stream(device=dev) for _ in engines] if groups > 1 else None
 
     names = W.PARAM_NAMES
     ix = W.indexes()
@@ -75,38 +82,45 @@ def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=Tr
     prior = {n: W.PRIOR_BOX.get(n, (0, np.inf)) for n in names}
     do_log = np.ones(len(names), dtype=bool)
     base_move = np.where(active, 0.003, 0.0)  # MCMC_script_writer.py:116
+    proposer = pt.Proposer(base_move, names, active, prior, do_log, ix)
 
-    def proposer(states, temps, rng):
-        return pt.propose(states, temps, base_move, names, active, prior, do_log, ix, rng)
-
-    return dict(eng=eng, ens0=ens0, T=T, d_T=d_T, evaluator=evaluator, proposer=proposer, times=times, vals=vals,
-                uncs=uncs, irf_tables=irf_tables)
+    return dict(eng=engines[0], engines=engines, ens0=ens0, T=T, d_T=d_T, evaluator=evaluators[0],
+                evaluators=evaluators, streams=streams, proposer=proposer, times=times, vals=vals, uncs=uncs,
+                irf_tables=irf_tables)
 
 
 def run(a, rank, world, local, dev, cpu_baseline_fn=None):
     import torch
     import torch.distributed as dist
     n_chains = a.chains
+    groups = max(1, int(getattr(a, "groups", 2)))
     S = setup(n_chains, dev, local, sort_by_cost=os.environ.get("MTRPL_NO_SORT") != "1",
-              parts=int(os.environ.get("MTRPL_PARTS", "2")))
-    eng, ens0, T, evaluator, proposer = S["eng"], S["ens0"], S["T"], S["evaluator"], S["proposer"]
-    ens = pt.PTEnsemble(ens0["chain_states"], T, evaluator, rank=rank, world=world)
+              parts=int(os.environ.get("MTRPL_PARTS", "2" if groups == 1 else "1")), groups=groups)
+    eng, ens0, T, proposer = S["eng"], S["ens0"], S["T"], S["proposer"]
+    # history-free draws (pt.PTEnsemble "counter" mode): the chain walked does not depend on N, on prefetching
+    # or on the chain groups (one engine + HIP stream each: the launch of one overlaps the host work of the other)
+    ens = pt.PTEnsemble(ens0["chain_states"], T, S["evaluators"] if groups > 1 else S["evaluator"], rank=rank,
+                        world=world, rng_mode="counter", streams=S["streams"])
     ens.initialise()
     temper_freq = 10
-    k = 0
-    for _ in range(a.warmup):
-        k += 1
-        ens.iterate(proposer, k % temper_freq == 0)
+    # Prefetching (pt.PTEnsemble.iterate2): when this rank's block leaves most SIMDs idle -- one solve occupies one
+    # SIMD for the whole launch -- evaluate iteration k+1's proposals for both outcomes of iteration k in the same
+    # launch: 3x the solves, 2 iterations per solve latency.  Pointless once the launch is throughput-bound.
+    slots = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+    local_solves = (ens.hi - ens.lo) * eng.M
+    mode = getattr(a, "prefetch", "auto")
+    # pays while a launch of 3x the solves takes less than two launches (measured: up to ~0.8 of the SIMD count)
+    prefetch = mode == "on" or (mode == "auto" and local_solves <= 0.8 * slots)
+    ens.advance(proposer, a.warmup, temper_freq, prefetch)
     torch.cuda.synchronize()
-    timing = eng.timing = []
+    timing = []
+    for e_ in S["engines"]:
+        e_.timing = timing
     if getattr(a, "use_dist", world > 1):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n_acc = 0
-    for _ in range(a.steps):
-        k += 1
-        n_acc += int(ens.iterate(proposer, k % temper_freq == 0).sum())
+    n_acc = ens.advance(proposer, a.steps, temper_freq, prefetch)
     torch.cuda.synchronize()
     if getattr(a, "use_dist", world > 1):
         dist.barrier()
@@ -125,6 +139,7 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
                                "IRF convolution (189 taps, dt 0.025 ns) + likelihood at all ladder temperatures on "
                                "device, all-gather of the ll table every iteration, swaps every 10",
                    "chains": n_chains, "solves_per_step": n_chains * 6, "parallelism": f"chain-blocks x{world}",
+                   "prefetch": bool(prefetch), "chain_groups": groups,
                    "forward_solves_per_sec": n_chains * 6 * a.steps / dt, "accepted_moves": n_acc,
                    "swap_accept_rate": float(ens.swap_accepts.sum() / max(1, ens.swap_attempts.sum())),
                    "mean_integrator_steps_rank0": float(stats[:, 0].mean()),

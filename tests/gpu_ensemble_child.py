@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--temper-freq", type=int, default=5)
     ap.add_argument("--port", type=int, default=29617)
     ap.add_argument("--force-min-y", type=int, default=1)
+    ap.add_argument("--rng-mode", default="stream")
+    ap.add_argument("--prefetch", type=int, default=0)
+    ap.add_argument("--groups", type=int, default=1)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     import torch
@@ -34,22 +37,24 @@ def main():
     from metrotrpl_amd import pt, pt_bench
     irf_raw = np.load(os.path.join(REPO, "tests", "golden", "irf.npz"))["irf745_raw"]
     S = pt_bench.setup(a.chains, dev, 0, irf_raw=irf_raw, parts=a.parts, sort_by_cost=bool(a.sort), split_min=0,
-                       sort_min=0, force_min_y=bool(a.force_min_y))
-    ens = pt.PTEnsemble(S["ens0"]["chain_states"], S["T"], S["evaluator"], rank=0, world=1)
+                       sort_min=0, force_min_y=bool(a.force_min_y), groups=a.groups)
+    ens = pt.PTEnsemble(S["ens0"]["chain_states"], S["T"], S["evaluators"] if a.groups > 1 else S["evaluator"], rank=0,
+                        world=1, rng_mode=a.rng_mode, streams=S["streams"])
     ens.initialise()
     table0 = ens.table.copy()
     n_parts = len(S["eng"]._cuts) - 1
-    swaps = 0
-    for k in range(1, a.iters + 1):
-        do_swap = k % a.temper_freq == 0
-        swaps += int(do_swap)
-        ens.iterate(S["proposer"], do_swap)
+    swaps = a.iters // a.temper_freq
+    calls = []
+    def spy(inner):
+        return lambda block, temps: (calls.append(block.shape[0]), inner(block, temps))[1]
+    ens.evaluators = [spy(ev) for ev in ens.evaluators]
+    n_acc = ens.advance(S["proposer"], a.iters, a.temper_freq, prefetch=bool(a.prefetch))
     torch.cuda.synchronize()
     backend = dist.get_backend() if (a.dist and dist.is_initialized()) else "none"
     np.savez(a.out, states0=S["ens0"]["chain_states"], table0=table0, states=ens.states, logll=ens.logll, table=ens.table,
              swap_attempts=ens.swap_attempts, swap_accepts=ens.swap_accepts, T=S["T"], times=S["times"],
              vals=np.array(S["vals"]), uncs=np.array(S["uncs"]), n_parts=n_parts, swaps=swaps, backend=np.array(backend),
-             ordered=np.array(S["eng"]._order is not None))
+             ordered=np.array(S["eng"]._order is not None), calls=np.array(calls), n_acc=n_acc)
     if a.dist:
         dist.destroy_process_group()
 

@@ -76,3 +76,22 @@ def test_config3_ensemble_through_rccl_and_two_streams(tmp_path):
         ref = rows[k]
         assert np.all(np.isfinite(ref))
         np.testing.assert_allclose(a["table0"][k], ref, rtol=1e-6, atol=1e-9 * np.max(np.abs(ref)), err_msg=f"chain {k}")
+
+
+def test_prefetched_ensemble_walks_the_same_chain(tmp_path):
+    """Two iterations per launch (192 states x 6 solves, both outcomes of the first evaluated ahead,
+    pt.PTEnsemble.iterate2) through RCCL == one iteration per launch, bit for bit, on the real evaluator."""
+    one = _child(tmp_path, "one", dist=0, parts=1, sort=0, rng_mode="counter", prefetch=0, iters=12, temper_freq=4)
+    two = _child(tmp_path, "two", dist=1, parts=1, sort=1, rng_mode="counter", prefetch=1, iters=12, temper_freq=4,
+                 port=29619)
+    assert list(one["calls"]) == [64] * 12 and list(two["calls"]) == [192] * 6
+    assert str(two["backend"]) == "nccl" and bool(two["ordered"])
+    for key in ("states", "logll", "table", "swap_attempts", "swap_accepts", "n_acc"):
+        np.testing.assert_array_equal(one[key], two[key], err_msg=key)
+    assert int(one["n_acc"]) > 0 and one["swap_attempts"].sum() == 3 * 63
+    # ... and cut into two chain groups, each with its own engine and HIP stream, launches overlapping
+    grp = _child(tmp_path, "grp", dist=1, parts=1, sort=1, rng_mode="counter", prefetch=1, iters=12, temper_freq=4,
+                 groups=2, port=29620)
+    assert list(grp["calls"]) == [96] * 12 and str(grp["backend"]) == "nccl"
+    for key in ("states", "logll", "table", "swap_attempts", "swap_accepts", "n_acc"):
+        np.testing.assert_array_equal(one[key], grp[key], err_msg=key)

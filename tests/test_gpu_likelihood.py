@@ -178,3 +178,70 @@ def test_loglik_long_traces(n, t_end):
     all3 = eng.eval(states, TEMPS)
     for c in range(3):
         np.testing.assert_array_equal(eng.eval(states[c:c + 1], TEMPS)[0], all3[c])
+
+
+def test_loglik_argmax_of_hand_made_traces():
+    """The fused kernel stops its argmax walk over the convolved trace once no later output can still win
+    (bound from the remaining samples).  Hand-made signals whose maximum is NOT where a decay has it --
+    late peak, two equal peaks, a ramp that tops out at the very end, a second peak one part in 10^9 taller,
+    a fast decay, a plateau followed by a late spike -- against the oracle's convolution, argmax shift,
+    trim and likelihood tail (laplace.py:44-126, trial_move_evaluation.py:117-165)."""
+    import torch
+    from metrotrpl_amd import _lib as L
+    from oracle import oracle as O
+    ev, state, uniq, shared = _setup("irf")
+    eng = _engine(state, uniq, shared)
+    n_tr = 7
+    M = eng.M
+    n_chains = -(-n_tr // M)
+    eng.upload(np.stack([np.asarray(state, dtype=float)] * n_chains))
+    T = torch.tensor(TEMPS, dtype=torch.float64, device=eng.dev)
+    eng.launch(T, len(TEMPS))
+    torch.cuda.synchronize()
+    nt = eng.nts[0]
+    assert all(n == nt for n in eng.nts)
+    t = np.asarray(shared["_times"][0], dtype=float)
+    span = t[-1]
+    bump = lambda c, w: np.exp(-((t - c) / w) ** 2)  # noqa: E731
+    traces = [
+        1e20 * (bump(0.7 * span, 0.05 * span) + 0.01),                       # late peak
+        1e20 * (bump(0.25 * span, 0.02 * span) + bump(0.75 * span, 0.02 * span) + 1e-3),   # twin peaks: first wins
+        1e18 * (1.0 + t / span),                                              # ramp: argmax at the end region
+        1e20 * (bump(0.2 * span, 0.03 * span) + (1 + 1e-9) * bump(0.8 * span, 0.03 * span) + 1e-3),  # second is taller
+        1e21 * np.exp(-t / (0.01 * span)) + 1e12,                             # fast decay: the walk stops early
+        1e19 * (1.0 + 50.0 * bump(0.97 * span, 0.004 * span)),                # plateau, spike near the end
+        1e20 * np.exp(-t / (0.5 * span)),                                     # slow decay
+    ]
+    sig = eng.d_sig.cpu().numpy().reshape(n_chains * M, nt).copy()
+    for k, y in enumerate(traces):
+        sig[k] = y
+    eng.d_sig.copy_(torch.from_numpy(sig.reshape(-1)))
+    eng.ctx.check(L.lib().mtrpl_loglik_batch_dev(eng.ctx.handle, eng.n_solves, eng.d_like.data_ptr(),
+                                                 eng.d_sig.data_ptr(), eng.d_t.data_ptr(), eng.d_exp_t.data_ptr(),
+                                                 eng.d_exp_y.data_ptr(), eng.d_exp_u.data_ptr(), T.data_ptr(),
+                                                 len(TEMPS), eng.max_nt, eng.d_ll.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    ll = eng.d_ll.cpu().numpy().reshape(n_chains * M, len(TEMPS))
+    raw = np.load(os.path.join(G, "irf.npz"))["irf745_raw"]
+    tab = O.make_I_tables({745: raw})[745]
+    shifts = []
+    for k, y in enumerate(traces):
+        m = k % M
+        ct, cy, ok = O.do_irf_convolution(t, y, tab, time_max_shift=True)
+        shifts.append(-ct[0])
+        ev_t = np.asarray(shared["_times"][m], dtype=float)
+        try:
+            sol, tc, vc, uc = O.post_conv_trim(ct, cy, ev_t, np.asarray(shared["_vals"][m]), np.asarray(shared["_uncs"][m]))
+            ref = O.loglik_tail(sol, vc, uc, 0.0, uniq["model_uncertainty"]["TRPL"], TEMPS)
+        except IndexError:  # nothing left of the experimental trace: the reference raises, the kernel says -inf
+            ok = False
+        if not ok:
+            ref = np.full(len(TEMPS), -np.inf)
+        if np.all(np.isfinite(ref)):
+            np.testing.assert_allclose(ll[k], ref, rtol=1e-9, err_msg=f"trace {k}")
+        else:
+            np.testing.assert_array_equal(ll[k], ref, err_msg=f"trace {k}")
+    # the cases really differ in where the maximum sits: early, middle, end
+    assert shifts[4] < 0.01 * span and 0.6 * span < shifts[0] < 0.8 * span and 0.2 * span < shifts[1] < 0.3 * span
+    assert shifts[3] > 0.7 * span and shifts[5] > 0.9 * span

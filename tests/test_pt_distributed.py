@@ -91,6 +91,105 @@ def test_sharded_ensemble_equals_serial(world, n_chains):
     assert ref.swap_attempts.sum() == 3 * (n_chains - 1)
 
 
+def _run_counter(n_chains, iters, prefetch, rank=0, world=1, temper_freq=4, groups=1):
+    ens0 = W.pt_ensemble(n_chains)
+    calls = []
+
+    def ev(block, temps):
+        calls.append(block.shape[0])
+        return _toy_evaluator(block, temps)
+    e = pt.PTEnsemble(ens0["chain_states"], ens0["temperatures"], ev if groups == 1 else [ev] * groups, rank=rank,
+                      world=world, rng_mode="counter")
+    e.initialise()
+    n_acc = e.advance(_proposer(), iters, temper_freq, prefetch=prefetch)
+    return e, n_acc, calls
+
+
+def test_prefetched_iterations_walk_the_same_chain():
+    """iterate2 (both outcomes of iteration k evaluated ahead) == one iteration at a time, bit for bit,
+    with half the evaluator launches between replica exchanges."""
+    n_chains, iters = 8, 23
+    seq, acc_s, calls_s = _run_counter(n_chains, iters, False)
+    pre, acc_p, calls_p = _run_counter(n_chains, iters, True)
+    assert acc_s == acc_p and 0 < acc_s < n_chains * iters
+    np.testing.assert_array_equal(pre.states, seq.states)
+    np.testing.assert_array_equal(pre.logll, seq.logll)
+    np.testing.assert_array_equal(pre.table, seq.table)
+    np.testing.assert_array_equal(pre.swap_accepts, seq.swap_accepts)
+    assert seq.swap_attempts.sum() == (iters // 4) * (n_chains - 1) and seq.swap_accepts.sum() > 0
+    assert pre.it == seq.it == iters
+    assert len(calls_s) == 1 + iters
+    # the exchange falls after even iterations, so every pair (1,2), (3,4), ... goes out as one launch
+    assert calls_p.count(3 * n_chains) == iters // 2 and len(calls_p) == 1 + iters // 2 + 1
+    odd, _, calls_o = _run_counter(n_chains, 9, True, temper_freq=3)  # an exchange between 3 and 4: no pair there
+    ref3, _, _ = _run_counter(n_chains, 9, False, temper_freq=3)
+    np.testing.assert_array_equal(odd.states, ref3.states)
+    assert calls_o[1:] == [3 * n_chains, n_chains, 3 * n_chains, n_chains, 3 * n_chains, n_chains]
+    with pytest.raises(RuntimeError):
+        pt.PTEnsemble(seq.states, seq.T, _toy_evaluator).iterate2(_proposer(), False)
+
+
+@pytest.mark.parametrize("groups,prefetch", [(2, False), (2, True), (3, True)])
+def test_chain_groups_walk_the_same_chain(groups, prefetch):
+    """The ensemble cut into interleaved chain groups, each with its own evaluator launches between two
+    replica exchanges (the pipelined form), == the whole ensemble one iteration at a time."""
+    n_chains, iters = 8, 19
+    seq, acc_s, _ = _run_counter(n_chains, iters, False)
+    grp, acc_g, calls = _run_counter(n_chains, iters, prefetch, groups=groups)
+    assert acc_g == acc_s and grp.it == iters and grp.git == [iters] * groups
+    np.testing.assert_array_equal(grp.states, seq.states)
+    np.testing.assert_array_equal(grp.logll, seq.logll)
+    np.testing.assert_array_equal(grp.table, seq.table)
+    np.testing.assert_array_equal(grp.swap_accepts, seq.swap_accepts)
+    sizes = sorted({len(range(g, n_chains, groups)) for g in range(groups)})
+    assert set(calls[1:]) <= {k * s_ for s_ in sizes for k in (1, 3)}
+    # iterate() / iterate2() on a grouped ensemble: every group, then the exchange
+    a = pt.PTEnsemble(seq.states, seq.T, [_toy_evaluator] * groups, rng_mode="counter")
+    b = pt.PTEnsemble(seq.states, seq.T, _toy_evaluator, rng_mode="counter")
+    a.initialise(), b.initialise()
+    acc_a = a.iterate2(_proposer(), True)
+    acc_b = (b.iterate(_proposer(), False), b.iterate(_proposer(), True))
+    for x, y in zip(acc_a, acc_b):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(a.states, b.states)
+    with pytest.raises(ValueError):
+        pt.PTEnsemble(seq.states, seq.T, [_toy_evaluator] * 2)  # groups need counter-mode draws
+
+
+def _prefetch_worker(rank, world, port, n_chains, iters, groups, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    e, n_acc, _ = _run_counter(n_chains, iters, True, rank, world, groups=groups)
+    q.put((rank, e.states.copy(), e.logll.copy(), e.swap_accepts.copy(), n_acc))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_chains,groups", [(2, 8, 1), (3, 8, 1), (2, 8, 2), (3, 7, 2)])
+def test_prefetched_sharded_ensemble_equals_serial(world, n_chains, groups):
+    """Three proposal sets per launch through ONE all-gather (even and uneven chain blocks), whole and in
+    chain groups."""
+    iters = 11
+    ref, acc_ref, _ = _run_counter(n_chains, iters, False)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_prefetch_worker, args=(r, world, port, n_chains, iters, groups, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=90) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, states, logll, swaps, n_acc in res:
+        np.testing.assert_array_equal(states, ref.states)
+        np.testing.assert_array_equal(logll, ref.logll)
+        np.testing.assert_array_equal(swaps, ref.swap_accepts)
+        assert n_acc == acc_ref
+
+
 def test_partition():
     assert pt.partition(512, 8) == [(64 * r, 64 * (r + 1)) for r in range(8)]
     assert pt.partition(8, 3) == [(0, 3), (3, 6), (6, 8)]
