@@ -158,9 +158,10 @@ def main():
     ap.add_argument("--prefetch", default="auto", choices=["auto", "on", "off"],
                     help="--workload pt: two Metropolis iterations per launch (both outcomes of the first "
                          "evaluated ahead); auto = when a rank's chain block leaves most SIMDs idle")
-    ap.add_argument("--groups", type=int, default=2,
+    ap.add_argument("--groups", type=int, default=0,
                     help="--workload pt: chain groups that run between two replica exchanges at their own pace, one "
-                         "HIP stream each (the launch of one overlaps the host work of the other)")
+                         "HIP stream each (the launch of one overlaps the host work of the other); 0 = 2 where a "
+                         "rank's chain block leaves SIMDs idle (the prefetching regime), else 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=2,
                     help="issue successive steps round-robin on this many HIP streams, so that the next batch fills "

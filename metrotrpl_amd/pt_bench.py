@@ -93,24 +93,26 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
     import torch
     import torch.distributed as dist
     n_chains = a.chains
-    groups = max(1, int(getattr(a, "groups", 2)))
+    # Prefetching (pt.PTEnsemble.iterate2): when this rank's block leaves most SIMDs idle -- one solve occupies one
+    # SIMD for the whole launch -- evaluate iteration k+1's proposals for both outcomes of iteration k in the same
+    # launch: 3x the solves, 2 iterations per solve latency.  Pays while a launch of 3x the solves takes less than
+    # two launches (measured: up to ~0.8 of the SIMD count); pointless once the launch is throughput-bound.
+    slots = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+    lo, hi = pt.partition(n_chains, world)[rank]
+    mode = getattr(a, "prefetch", "auto")
+    prefetch = mode == "on" or (mode == "auto" and (hi - lo) * 6 <= 0.8 * slots)
+    # chain groups (one engine + HIP stream each: the launch of one overlaps the host work and the likelihood
+    # tail of the other): the same latency-bound regime
+    groups = int(getattr(a, "groups", 0)) or (2 if prefetch else 1)
     S = setup(n_chains, dev, local, sort_by_cost=os.environ.get("MTRPL_NO_SORT") != "1",
               parts=int(os.environ.get("MTRPL_PARTS", "2" if groups == 1 else "1")), groups=groups)
     eng, ens0, T, proposer = S["eng"], S["ens0"], S["T"], S["proposer"]
     # history-free draws (pt.PTEnsemble "counter" mode): the chain walked does not depend on N, on prefetching
-    # or on the chain groups (one engine + HIP stream each: the launch of one overlaps the host work of the other)
+    # or on the chain groups
     ens = pt.PTEnsemble(ens0["chain_states"], T, S["evaluators"] if groups > 1 else S["evaluator"], rank=rank,
                         world=world, rng_mode="counter", streams=S["streams"])
     ens.initialise()
     temper_freq = 10
-    # Prefetching (pt.PTEnsemble.iterate2): when this rank's block leaves most SIMDs idle -- one solve occupies one
-    # SIMD for the whole launch -- evaluate iteration k+1's proposals for both outcomes of iteration k in the same
-    # launch: 3x the solves, 2 iterations per solve latency.  Pointless once the launch is throughput-bound.
-    slots = 4 * torch.cuda.get_device_properties(dev).multi_processor_count
-    local_solves = (ens.hi - ens.lo) * eng.M
-    mode = getattr(a, "prefetch", "auto")
-    # pays while a launch of 3x the solves takes less than two launches (measured: up to ~0.8 of the SIMD count)
-    prefetch = mode == "on" or (mode == "auto" and local_solves <= 0.8 * slots)
     ens.advance(proposer, a.warmup, temper_freq, prefetch)
     torch.cuda.synchronize()
     timing = []
