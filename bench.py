@@ -167,6 +167,9 @@ def main():
                     help="issue successive steps round-robin on this many HIP streams, so that the next batch fills "
                          "the SIMDs freed by the early finishers of the previous one (1: back-to-back launches on one "
                          "stream -- always measured as well and reported as config.single_stream)")
+    ap.add_argument("--no-single-stream", action="store_true",
+                    help="skip the one-stream pass before the timed region (profiling runs: the kernel statistics "
+                         "then hold the timed kind of launch only)")
     ap.add_argument("--sort-by-cost", type=int, default=1,
                     help="issue the solves of the batch longest first (order measured in a warm-up launch)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
@@ -281,7 +284,7 @@ def main():
 
     # the same K steps back to back on ONE stream first (each launch alone on the device: the latency figure
     # and the kernel's own speed), then the timed region the headline value comes from
-    dt1, kern1_ms = timed(1) if S > 1 else (None, None)
+    dt1, kern1_ms = timed(1) if S > 1 and not a.no_single_stream else (None, None)
     dt, kern_ms = timed(S)
     if S == 1:
         dt1, kern1_ms = dt, kern_ms
@@ -328,14 +331,16 @@ def main():
                        **({"options": a.opt} if a.opt else {}),
                        "streams": S, "issue_order": "longest first (measured in the warm-up launch)" if a.sort_by_cost
                        else "as drawn",
-                       "single_stream": {"solves_per_sec": world * B * a.steps / dt1, "ms_per_step": dt1 / a.steps * 1e3,
-                                         "note": "the same K steps back to back on one HIP stream (every launch alone on "
-                                                 "the device), measured in this run before the timed region"}},
+                       "single_stream": None if dt1 is None else {
+                           "solves_per_sec": world * B * a.steps / dt1, "ms_per_step": dt1 / a.steps * 1e3,
+                           "note": "the same K steps back to back on one HIP stream (every launch alone on the device), "
+                                   "measured in this run before the timed region"}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, **pmc, "kernel": "solve_kernel_wave",
                          "kernel_ms": kern_ms, "launches_in_flight": S, "algorithmic_bytes_per_solve": A,
-                         "single_stream": {"kernel_ms": kern1_ms, "achieved": A * B / (kern1_ms * 1e-3) / 1e9,
-                                           "frac": A * B / (kern1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "single_stream": None if kern1_ms is None else {
+                             "kernel_ms": kern1_ms, "achieved": A * B / (kern1_ms * 1e-3) / 1e9,
+                             "frac": A * B / (kern1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "measured_stream_copy": copy_gbs,
                          "note": "state-streaming model of SURVEY.md 8d; the solve state is register-resident by "
                                  "design, so HBM is not the limiter (see DESIGN.md)"},

@@ -160,7 +160,7 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
                             "frac": achieved / HBM_PEAK_GBS, "kernel": "solve_kernel_wave", "kernel_ms": kern_ms,
                             "solves_per_launch": float(np.mean(n_solve)), "launches_per_step": len(timing) / max(1, a.steps),
                             "algorithmic_bytes_per_solve": A, "loglik_kernel_ms": float(np.mean(t_like)),
-                            **pmc_fields(),
+                            **pmc_fields(float(np.mean(n_solve)) / 1024.0),
                             "note": "state-streaming model of SURVEY.md 8d incl. the 8*(3*nk+2) IRF term; the solve state "
                                     "is register-resident by design, so HBM is not the limiter (DESIGN.md section 4)"}
         if cpu_baseline_fn is not None and world == 1 and not getattr(a, "no_cpu_baseline", False):
@@ -180,15 +180,18 @@ def algorithmic_bytes(nx, nt, model="std", irf_nk=0):
     return a
 
 
-def pmc_fields():
+def pmc_fields(launch_scale=1.0):
     """Counter-derived figures of the solve kernel from the committed rocprofv3 --pmc summary (they are not
-    measured in this run; traffic_source says where they come from)."""
+    measured in this run; traffic_source says where they come from).  launch_scale: solves per launch here /
+    the 1024 of the profiled launch (the traffic is per solve: descriptor in, samples out)."""
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tp = os.path.join(repo, "profiles", "hbm_traffic.json")
     out = {"traffic": None, "traffic_source": None}
     try:
         z = json.load(open(tp))
         out["traffic"] = z.get("solve_kernel_bytes_per_launch")
+        if out["traffic"] is not None and launch_scale != 1.0:
+            out["traffic"] = out["traffic"] * launch_scale
         out["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the config-2 launch)"
         d = z.get("derived", {})
         out["valu_active_frac"] = d.get("valu_active_fraction_of_wave_cycles")

@@ -21,7 +21,7 @@ for d in sys.argv[3:]:
             vals[c] = sum(v) / len(v)  # average per launch
 fetch, write = vals.get("FETCH_SIZE"), vals.get("WRITE_SIZE")
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, --kernel-trace only) on "
-                 "`python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`; kernel " + kern + ", average per launch (1024 solves)",
+                 "`python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --streams 1 --sort-by-cost 0` (one launch at a time on the device); kernel " + kern + ", average per launch (1024 solves)",
        "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
        "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE reports 1/2 of a wide coalesced read on gfx950 -> doubled; "
                      "WRITE_SIZE exact; both in KiB.  Reads here are small descriptor/time-grid loads, so the factor is an upper bound.",
