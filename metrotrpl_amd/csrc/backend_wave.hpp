@@ -231,9 +231,15 @@ struct WaveBackend {
         const V2 re_up = vnext(r[0]);
         const V2 t1 = mvec(get(CR_AL), r[0]), t2 = mvec(get(CR_GA), re_up);
         V2 rk{r[1].x - t1.x - t2.x, r[1].y - t1.y - t2.y};
+        // The elimination blocks of level lv+1 are requested from LDS before the exchange of level lv is waited
+        // for: their latency hides behind it instead of following it (one wave per SIMD: nothing else would hide
+        // it).  One LDS round trip per level instead of two: 6.08 -> 5.74 ms per 1024-solve launch.
+        M2 al = get(PAL0), ga = get(PGA0);
 #pragma unroll
         for (int lv = 0; lv < 6; ++lv) {
             const int s = 1 << lv;
+            M2 al_n = al, ga_n = ga;
+            if (lv < 5) { al_n = get(PAL0 + lv + 1); ga_n = get(PGA0 + lv + 1); }
             V2 rm, rp;
             if (lv == 0) {          // nearest neighbours: DPP wave shifts
                 rm = vprev(rk);
@@ -244,8 +250,10 @@ struct WaveBackend {
                 rm = vshf(rk, (lane - s) & 63);
                 rp = vshf(rk, (lane + s) & 63);
             }
-            const V2 u1 = mvec(get(PAL0 + lv), rm), u2 = mvec(get(PGA0 + lv), rp);
+            const V2 u1 = mvec(al, rm), u2 = mvec(ga, rp);
             rk = V2{rk.x - u1.x - u2.x, rk.y - u1.y - u2.y};
+            al = al_n;
+            ga = ga_n;
         }
         const V2 xk = mvec(Bfin, rk);
         const V2 xk_prev = vprev(xk);
