@@ -12,17 +12,14 @@ synthetic batch per GPU, nx=128, thickness 2000 nm, 1001 output times over
 (weak scaling, no data-path collective: solves are independent).
 
 The K timed steps are independent batches, so they are issued the way a caller with
-more than one batch to do issues them: round-robin on two HIP streams, each batch's
-solves longest first -- a solve holds one SIMD for its whole duration and durations
-spread 1:1.5, so the SIMDs the short solves of one launch free go to the next
-launch's long ones instead of idling until the slowest solve is done.  The same K
-steps back to back on ONE stream (every launch alone on the device: the latency
-figure) are measured in the same run and reported as config.single_stream /
-roofline.single_stream.
-
-`--workload pt` runs the parallel-tempering power-scan instead (configs[2]/[3]:
-chains x 6 measurements, IRF convolution + likelihood on the device, RCCL
-all-gather of the per-chain log-likelihood table each step; strong scaling).
+more than one batch to do issues them: round-robin on three HIP streams, each batch's
+solves longest first, on the two-solves-per-SIMD form of the wave kernel -- a solve
+holds its SIMD slot for its whole duration, durations spread 1:1.5 and a wave alone on
+a SIMD leaves half the issue slots waiting on LDS latency, so the slots the short
+solves of one launch free go to the next launch's long ones and a second resident
+wave fills the waits of the first.  The same K steps back to back on ONE stream with
+one solve per SIMD (every launch alone on the device: the latency figure) are measured
+in the same run and reported as config.single_stream / roofline.single_stream.
 
 Prints ONE JSON line on rank 0.
 """
@@ -163,7 +160,7 @@ def main():
                          "HIP stream each (the launch of one overlaps the host work of the other); 0 = 2 where a "
                          "rank's chain block leaves SIMDs idle (the prefetching regime), else 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="issue successive steps round-robin on this many HIP streams, so that the next batch fills "
                          "the SIMDs freed by the early finishers of the previous one (1: back-to-back launches on one "
                          "stream -- always measured as well and reported as config.single_stream)")
@@ -218,9 +215,11 @@ def main():
         return
 
     ctx = L.Context(local)
+    user_variant = False
     for kv in a.opt:
         k, v = kv.split("=")
         ctx.set_option(k, float(v))
+        user_variant = user_variant or k in ("kernel_variant", "two_per_simd_min_batch")
     B = a.batch
     # rank r takes draws [r*B, (r+1)*B) of the seeded config-2 stream
     c = W.config2(B * world)
@@ -285,6 +284,13 @@ def main():
     # the same K steps back to back on ONE stream first (each launch alone on the device: the latency figure
     # and the kernel's own speed), then the timed region the headline value comes from
     dt1, kern1_ms = timed(1) if S > 1 and not a.no_single_stream else (None, None)
+    if S > 1 and not user_variant:
+        # several launches in flight: more solves than SIMDs, so the two-solves-per-SIMD form of the wave kernel
+        # (a launch on its own would pick it from 1025 solves on)
+        ctx.set_option("two_per_simd_min_batch", 1)
+        for k in range(S):
+            step(k)
+        torch.cuda.synchronize()
     dt, kern_ms = timed(S)
     if S == 1:
         dt1, kern1_ms = dt, kern_ms
@@ -316,7 +322,8 @@ def main():
         A = algorithmic_bytes_per_solve(c["nx"], nt)
         achieved = A * B / (kern_ms * 1e-3) / 1e9
         from metrotrpl_amd.pt_bench import pmc_fields
-        pmc = pmc_fields()
+        kern_name = "solve_kernel_wave2" if (S > 1 and not user_variant) else "solve_kernel_wave"
+        pmc = pmc_fields(B, kern_name)
         line = {
             "metric": "trpl_forward_solves_per_sec", "value": world * B * a.steps / dt, "unit": "solves/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -329,14 +336,15 @@ def main():
                        "all_solves_ok": ok, "mean_integrator_steps": float(stats[:, 0].mean()),
                        "mean_rhs_evals": float(stats[:, 1].mean()), "max_integrator_steps": int(stats[:, 0].max()),
                        **({"options": a.opt} if a.opt else {}),
-                       "streams": S, "issue_order": "longest first (measured in the warm-up launch)" if a.sort_by_cost
+                       "streams": S, "solves_per_simd": 2 if (S > 1 and not user_variant) else "as set by --opt" if user_variant
+                       else 1, "issue_order": "longest first (measured in the warm-up launch)" if a.sort_by_cost
                        else "as drawn",
                        "single_stream": None if dt1 is None else {
                            "solves_per_sec": world * B * a.steps / dt1, "ms_per_step": dt1 / a.steps * 1e3,
                            "note": "the same K steps back to back on one HIP stream (every launch alone on the device), "
                                    "measured in this run before the timed region"}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, **pmc, "kernel": "solve_kernel_wave",
+                         "frac": achieved / HBM_PEAK_GBS, **pmc, "kernel": kern_name,
                          "kernel_ms": kern_ms, "launches_in_flight": S, "algorithmic_bytes_per_solve": A,
                          "single_stream": None if kern1_ms is None else {
                              "kernel_ms": kern1_ms, "achieved": A * B / (kern1_ms * 1e-3) / 1e9,

@@ -17,8 +17,15 @@
 namespace mtrpl {
 
 constexpr int kFactorLdsBytes = 17 * 2 * 64 * 16;  // 34816 B per wave
+constexpr int kFactorLdsBytesF32 = 17 * 64 * 16;     // 17408 B per wave with blocks stored as 4 floats
 
-struct WaveBackend {
+// F32BLK: the elimination blocks are STORED rounded to fp32 (one 16-byte row per block and lane), all
+// arithmetic stays fp64.  The blocks only define the approximate inverse the simplified Newton iteration
+// uses, the residual is fp64: the iteration converges to the same corrector solution (measured: same step
+// counts, +0.7 % Newton iterations, per-decade accuracy table unchanged).  Halves the LDS slab, which is
+// what lets two solves share a SIMD (solve_kernel_wave2).
+template <bool F32BLK>
+struct WaveBackendT {
     using real = double;
     static constexpr int R = 2, V = 6;
     static constexpr bool TRAPS = false;
@@ -35,19 +42,23 @@ struct WaveBackend {
     // The 17 elimination blocks (in-lane CR: Binv_e, BiA_e, BiC_e, cr_al, cr_ga; PCR: al[6], ga[6]) live
     // in this wave's LDS slab: [17 blocks][2 halves][64 lanes] x 16 B, i.e. every access is a
     // conflict-free ds_read/write_b128 (lane stride 16 B).
-    double2 *lds;
+    void *lds;
     enum { BINV_E = 0, BIA_E, BIC_E, CR_AL, CR_GA, PAL0, PGA0 = PAL0 + 6, NBLK = PGA0 + 6 };
 
     int lds_off;  // lane * 16: byte offset of this lane's 16-byte row inside a block row
-    __device__ inline WaveBackend(int lane_, double2 *lds_) : lane(lane_), lds(lds_), lds_off(lane_ * 16) {}
+    __device__ inline WaveBackendT(int lane_, void *lds_) : lane(lane_), lds(lds_), lds_off(lane_ * 16) {}
     __device__ inline void set_problem(const ParT<real> &p_, int L_) { p = p_; L = L_; }
     __device__ inline int node(int r) const { return lane * R + r; }
     __device__ inline bool leader() const { return lane == 0; }
 
     __device__ inline void put(int blk, const M2 &m) const
     {
-        lds[(blk * 2 + 0) * 64 + lane] = double2{m.a, m.b};
-        lds[(blk * 2 + 1) * 64 + lane] = double2{m.c, m.d};
+        if (F32BLK) {
+            static_cast<float4 *>(lds)[blk * 64 + lane] = float4{(float)m.a, (float)m.b, (float)m.c, (float)m.d};
+        } else {
+            static_cast<double2 *>(lds)[(blk * 2 + 0) * 64 + lane] = double2{m.a, m.b};
+            static_cast<double2 *>(lds)[(blk * 2 + 1) * 64 + lane] = double2{m.c, m.d};
+        }
     }
     __device__ inline M2 get(int blk)
     {
@@ -56,7 +67,11 @@ struct WaveBackend {
         // push the history out to AGPRs (measured: AGPRs 256 -> 116, 12.8 -> 12.3 ms per 1024-solve batch).
         // The offset register itself is declared modified, so hiding it costs no instruction.
         asm volatile("" : "+v"(lds_off));
-        const char *base = reinterpret_cast<const char *>(lds) + lds_off;
+        const char *base = static_cast<const char *>(lds) + lds_off;
+        if (F32BLK) {
+            const float4 q = *reinterpret_cast<const float4 *>(base + blk * 1024);
+            return M2{(double)q.x, (double)q.y, (double)q.z, (double)q.w};
+        }
         const double2 u = *reinterpret_cast<const double2 *>(base + (blk * 2 + 0) * 1024);
         const double2 v = *reinterpret_cast<const double2 *>(base + (blk * 2 + 1) * 1024);
         return M2{u.x, u.y, v.x, v.y};
@@ -266,6 +281,8 @@ struct WaveBackend {
     }
 };
 
+using WaveBackend = WaveBackendT<false>;
+
 __global__ __launch_bounds__(64, 1) void solve_kernel_wave(const mtrpl_solve_desc *__restrict__ descs,
                                                             const double *__restrict__ ini,
                                                             const double *__restrict__ tsteps,
@@ -277,6 +294,19 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_wave(const mtrpl_solve_des
     if (sidx >= B) return;
     __shared__ double2 fac_lds[kFactorLdsBytes / 16];
     WaveBackend bk(threadIdx.x & 63, fac_lds);
+    integrate(bk, descs[sidx], ini, tsteps, out, status, stats, sidx, tune, clk0_);
+}
+
+// Two solves per SIMD: fp32-stored blocks (17 KB of LDS per wave, 8 waves per CU) and a 256-register budget.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void solve_kernel_wave2(
+    const mtrpl_solve_desc *__restrict__ descs, const double *__restrict__ ini, const double *__restrict__ tsteps,
+    double *__restrict__ out, int32_t *__restrict__ status, int32_t *__restrict__ stats, int64_t B, SolveTuning tune)
+{
+    const int64_t sidx = blockIdx.x;
+    const unsigned long long clk0_ = __builtin_amdgcn_s_memtime();
+    if (sidx >= B) return;
+    __shared__ float4 fac_lds[kFactorLdsBytesF32 / 16];
+    WaveBackendT<true> bk(threadIdx.x & 63, fac_lds);
     integrate(bk, descs[sidx], ini, tsteps, out, status, stats, sidx, tune, clk0_);
 }
 

@@ -48,6 +48,8 @@ struct mtrpl_ctx {
     int kernel_variant = 0;  // see include/metrotrpl_amd.h
     int precision = 64;      // 64: fp64 (the product); 32: the fp32 build of the team kernel (precision sweep only)
     size_t like_lds_attr = 64 * 1024;  // dynamic-LDS limit the likelihood kernel has been raised to
+    int two_per_simd_min_batch = 1025;  // kernel_variant 0: launches of at least this many std / nx <= 128 solves use
+                                        // the two-solves-per-SIMD wave kernel (more than one solve per SIMD anyway)
     int pair_max_batch = 0;  // kernel_variant 0: launches up to this many solves use the wave-pair kernel (0: never --
                              // measured: its exchanges cost what the halved per-lane work saves)
 };
@@ -201,14 +203,15 @@ __device__ inline void newton_probe(BK &bk, const double *par, const double *dxs
     }
     if (bk.leader()) x[s * S + 3 * L] = b[s * S + 3 * L];  // E_0 and E_L rows of I - cJ are identity rows
 }
+template <bool F32BLK>
 __global__ __launch_bounds__(64) void newton_probe_kernel_wave(const double *par, const double *dxs, const double *cs,
                                                                const double *y, const double *b, double *x, int nx,
                                                                int64_t B)
 {
     const int64_t s = blockIdx.x;
     if (s >= B) return;
-    __shared__ double2 fac_lds[kFactorLdsBytes / 16];
-    WaveBackend bk(threadIdx.x, fac_lds);
+    __shared__ double2 fac_lds[(F32BLK ? kFactorLdsBytesF32 : kFactorLdsBytes) / 16];
+    WaveBackendT<F32BLK> bk(threadIdx.x, fac_lds);
     newton_probe(bk, par, dxs, cs, y, b, x, nx, s);
 }
 template <int W, int NREG>
@@ -423,11 +426,13 @@ int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value)
         if (k == o.key) { ctx->tune.*(o.m) = (int)value; return MTRPL_OK; }
     if (k == "kernel_variant") {
         const int v = (int)value;
-        if (v != 0 && v != 1 && v != 2 && v != 4 && v != 5)
-            return bad(ctx, MTRPL_ERR_BAD_ARG, "kernel_variant must be 0 (auto), 1 (team), 2 (wave), 4 or 5 (wave pair)");
+        if (v != 0 && v != 1 && v != 2 && v != 3 && v != 4 && v != 5)
+            return bad(ctx, MTRPL_ERR_BAD_ARG, "kernel_variant must be 0 (auto), 1 (team), 2 (wave), 3 (wave, two per SIMD), 4 or 5 (wave pair)");
         ctx->kernel_variant = v;
     } else if (k == "pair_max_batch") {
         ctx->pair_max_batch = (int)value;
+    } else if (k == "two_per_simd_min_batch") {
+        ctx->two_per_simd_min_batch = (int)value;
     } else if (k == "precision") {
         if (value != 32 && value != 64) return bad(ctx, MTRPL_ERR_BAD_ARG, "precision must be 32 or 64");
         ctx->precision = (int)value;
@@ -447,6 +452,7 @@ int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value)
         if (k == o.key) { *value = ctx->tune.*(o.m); return MTRPL_OK; }
     if (k == "kernel_variant") *value = ctx->kernel_variant;
     else if (k == "pair_max_batch") *value = ctx->pair_max_batch;
+    else if (k == "two_per_simd_min_batch") *value = ctx->two_per_simd_min_batch;
     else if (k == "precision") *value = ctx->precision;
     else return MTRPL_ERR_BAD_ARG;
     return MTRPL_OK;
@@ -472,11 +478,15 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
         return MTRPL_OK;
     }
     // std model, nx <= 128: the register-resident backends.
-    //   wave (2):  one wave per solve, two nodes per lane -- most solves per second in a full launch
+    //   wave (2):  one wave per solve, two nodes per lane, one solve per SIMD -- the shortest solve
+    //   wave (3):  the same with the elimination blocks stored as fp32 and a 256-register budget: two solves
+    //              per SIMD, each ~12 % slower alone, 1.3-1.4x the solves per second once the SIMDs are
+    //              over-subscribed (the second wave fills the issue slots the first leaves waiting on LDS)
     //   pair (4):  two waves per solve, one node per lane, blocks in registers (opt-in: pair_max_batch)
     //   pair (5):  the same with every block in LDS and a register budget for two waves per SIMD
     int variant = ctx->kernel_variant;
-    if (variant == 0) variant = (!traps && max_nx <= 128 && B <= ctx->pair_max_batch) ? 4 : 2;
+    if (variant == 0)
+        variant = (!traps && max_nx <= 128 && B <= ctx->pair_max_batch) ? 4 : ((B >= ctx->two_per_simd_min_batch) ? 3 : 2);
     if (traps || max_nx > 128 || variant == 1) {
         const int rc = launch_team_any<double>(ctx, s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, max_nx, traps);
         if (rc != MTRPL_OK) return rc;
@@ -487,6 +497,9 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
         if (max_nx <= 64) { if (variant == 4) MTRPL_PAIR(1, 6, 1); else MTRPL_PAIR(1, 0, 2); }
         else { if (variant == 4) MTRPL_PAIR(2, 3, 1); else MTRPL_PAIR(2, 0, 2); }
 #undef MTRPL_PAIR
+    } else if (variant == 3) {
+        hipLaunchKernelGGL(solve_kernel_wave2, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
+                           d_status, d_stats, B, ctx->tune);
     } else {
         hipLaunchKernelGGL(solve_kernel_wave, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
                            d_status, d_stats, B, ctx->tune);
@@ -598,8 +611,10 @@ int mtrpl_newton_probe(mtrpl_ctx *ctx, int64_t B, int32_t nx, const double *par,
         else if (nx <= 64) hipLaunchKernelGGL((newton_probe_kernel_pair<1, 0>), dim3((unsigned)B), dim3(64), MTRPL_NP_ARGS);
         else if (variant == 4) hipLaunchKernelGGL((newton_probe_kernel_pair<2, 3>), dim3((unsigned)B), dim3(128), MTRPL_NP_ARGS);
         else hipLaunchKernelGGL((newton_probe_kernel_pair<2, 0>), dim3((unsigned)B), dim3(128), MTRPL_NP_ARGS);
+    } else if (variant == 3) {
+        hipLaunchKernelGGL(newton_probe_kernel_wave<true>, dim3((unsigned)B), dim3(64), MTRPL_NP_ARGS);
     } else {
-        hipLaunchKernelGGL(newton_probe_kernel_wave, dim3((unsigned)B), dim3(64), MTRPL_NP_ARGS);
+        hipLaunchKernelGGL(newton_probe_kernel_wave<false>, dim3((unsigned)B), dim3(64), MTRPL_NP_ARGS);
     }
 #undef MTRPL_NP_ARGS
     HIP_TRY(ctx, hipGetLastError());

@@ -104,6 +104,9 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
     # chain groups (one engine + HIP stream each: the launch of one overlaps the host work and the likelihood
     # tail of the other): the same latency-bound regime
     groups = int(getattr(a, "groups", 0)) or (2 if prefetch else 1)
+    for kv in getattr(a, "opt", []) or []:
+        k_, v_ = kv.split("=")
+        L.default_context(local).set_option(k_, float(v_))
     S = setup(n_chains, dev, local, sort_by_cost=os.environ.get("MTRPL_NO_SORT") != "1",
               parts=int(os.environ.get("MTRPL_PARTS", "2" if groups == 1 else "1")), groups=groups)
     eng, ens0, T, proposer = S["eng"], S["ens0"], S["T"], S["proposer"]
@@ -155,12 +158,14 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
         t_like = [e1.elapsed_time(e2) for e0, e1, e2, n in timing]
         n_solve = [n for *_, n in timing]
         kern_ms = float(np.mean(t_solve))
+        # launches of more than 1024 solves go to the two-solves-per-SIMD form of the wave kernel (include/metrotrpl_amd.h)
+        kern_name = "solve_kernel_wave2" if float(np.mean(n_solve)) >= 1025 else "solve_kernel_wave"
         achieved = A * float(np.mean(n_solve)) / (kern_ms * 1e-3) / 1e9
         line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": achieved / HBM_PEAK_GBS, "kernel": "solve_kernel_wave", "kernel_ms": kern_ms,
+                            "frac": achieved / HBM_PEAK_GBS, "kernel": kern_name, "kernel_ms": kern_ms,
                             "solves_per_launch": float(np.mean(n_solve)), "launches_per_step": len(timing) / max(1, a.steps),
                             "algorithmic_bytes_per_solve": A, "loglik_kernel_ms": float(np.mean(t_like)),
-                            **pmc_fields(float(np.mean(n_solve)) / 1024.0),
+                            **pmc_fields(float(np.mean(n_solve)), kern_name),
                             "note": "state-streaming model of SURVEY.md 8d incl. the 8*(3*nk+2) IRF term; the solve state "
                                     "is register-resident by design, so HBM is not the limiter (DESIGN.md section 4)"}
         if cpu_baseline_fn is not None and world == 1 and not getattr(a, "no_cpu_baseline", False):
@@ -180,19 +185,19 @@ def algorithmic_bytes(nx, nt, model="std", irf_nk=0):
     return a
 
 
-def pmc_fields(launch_scale=1.0):
-    """Counter-derived figures of the solve kernel from the committed rocprofv3 --pmc summary (they are not
-    measured in this run; traffic_source says where they come from).  launch_scale: solves per launch here /
-    the 1024 of the profiled launch (the traffic is per solve: descriptor in, samples out)."""
+def pmc_fields(solves_per_launch=1024, kernel="solve_kernel_wave"):
+    """Counter-derived figures of the solve kernel from the committed rocprofv3 --pmc summaries (they are not
+    measured in this run; traffic_source says where they come from).  The traffic is per solve -- descriptor
+    in, samples out -- and is scaled from the profiled launch to `solves_per_launch`."""
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tp = os.path.join(repo, "profiles", "hbm_traffic.json")
+    name = "hbm_traffic_wave2.json" if kernel.endswith("wave2") else "hbm_traffic.json"
     out = {"traffic": None, "traffic_source": None}
     try:
-        z = json.load(open(tp))
+        z = json.load(open(os.path.join(repo, "profiles", name)))
         out["traffic"] = z.get("solve_kernel_bytes_per_launch")
-        if out["traffic"] is not None and launch_scale != 1.0:
-            out["traffic"] = out["traffic"] * launch_scale
-        out["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the config-2 launch)"
+        if out["traffic"] is not None:
+            out["traffic"] = out["traffic"] * solves_per_launch / float(z.get("solves_per_launch", 1024))
+        out["traffic_source"] = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of {kernel}, one launch at a time)"
         d = z.get("derived", {})
         out["valu_active_frac"] = d.get("valu_active_fraction_of_wave_cycles")
         out["occupancy_waves_per_simd"] = d.get("occupancy_waves_per_simd", 1)

@@ -31,9 +31,19 @@ def per_decade(sig, ref):
     return out
 
 
+@pytest.mark.parametrize("variant", [0, 3])  # the default kernel choice | two solves per SIMD, fp32-stored blocks
 @pytest.mark.parametrize("part", ["config2", "config3"])
-def test_every_decade_of_every_trace(part):
-    from metrotrpl_amd import batch
+def test_every_decade_of_every_trace(part, variant):
+    from metrotrpl_amd import _lib as L, batch
+    ctx = L.default_context()
+    ctx.set_option("kernel_variant", variant)
+    try:
+        _every_decade(part, batch)
+    finally:
+        ctx.set_option("kernel_variant", 0)
+
+
+def _every_decade(part, batch):
     z = np.load(os.path.join(G, "tail_decades.npz"))
     n2 = int(z["n_cfg2"])
     sel = slice(0, n2) if part == "config2" else slice(n2, None)

@@ -91,6 +91,7 @@ def test_newton_linear_solver():
     ix, un = W.indexes(), W.units()
     c2 = W.config2(6)
     rng = np.random.default_rng(0)
+    worst_f32 = 0.0
     for nx in (128, 100, 37):
         for k in range(6):
             th = 2000.0 if k % 2 else 311.0
@@ -105,15 +106,23 @@ def test_newton_linear_solver():
                 b[2 * nx] = 0.0
                 b[-1] = 0.0
                 x_ref = np.linalg.solve(M, b)
-                for variant in (2, 4, 5):  # one wave | wave pair, blocks in registers | wave pair, blocks in LDS
+                # one wave | one wave, blocks stored as fp32 | wave pair, blocks in registers | wave pair, blocks in LDS
+                for variant in (2, 3, 4, 5):
                     ctx.set_option("kernel_variant", variant)
                     try:
                         x = batch.newton_probe(par, [prob.dx], [c], y[None, :], b[None, :], nx)[0]
                     finally:
                         ctx.set_option("kernel_variant", 0)
                     res = np.linalg.norm(M @ x - b) / np.linalg.norm(b)
+                    if variant == 3:
+                        # the blocks are rounded to fp32 on their way into LDS: an approximate inverse, good for a
+                        # contraction of the simplified Newton iteration by three orders of magnitude per sweep
+                        assert res < 1e-3, (variant, nx, k, c, res)
+                        worst_f32 = max(worst_f32, res)
+                        continue
                     assert res < 1e-6, (variant, nx, k, c, res)
                     np.testing.assert_allclose(x, x_ref, rtol=1e-5, atol=1e-7 * np.max(np.abs(x_ref)))
+    print(f"fp32-stored blocks: worst relative residual {worst_f32:.1e}")
 
 
 def _run(c, rtol=None, atol=None):
@@ -257,15 +266,16 @@ def test_hard_cases_tauP_much_larger_than_tauN():
 
 
 def test_every_backend_lands_on_the_converged_traces():
-    """kernel_variant 2 (one wave per solve), 4 / 5 (wave pair: SPIKE interface between the waves, blocks in
-    registers / in LDS) and 1 (team kernel) are four different distributions of the same integrator: all
-    within the gate on the hard cases, and not one kernel behind four switches."""
+    """kernel_variant 2 (one wave per solve), 3 (the same, elimination blocks stored as fp32, two solves per SIMD),
+    4 / 5 (wave pair: SPIKE interface between the waves, blocks in registers / in LDS) and 1 (team kernel) are
+    different distributions of the same integrator: all within the gate on the hard cases, and not one kernel
+    behind five switches."""
     from metrotrpl_amd import _lib as L, batch
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "hard_cases.npz"))
     idx = {n: i for i, n in enumerate(str(z["names"]).split(","))}
     ctx = L.default_context()
     out = {}
-    variants = (2, 4, 5, 1)
+    variants = (2, 3, 4, 5, 1)
     try:
         for variant in variants:
             ctx.set_option("kernel_variant", variant)
@@ -280,18 +290,25 @@ def test_every_backend_lands_on_the_converged_traces():
         m = np.abs(ref) >= 1e-4 * abs(ref[0])
         for variant in variants:
             assert np.max(np.abs(out[variant][k][m] - ref[m]) / np.abs(ref[m])) <= 1e-6, (variant, k)
-    assert not np.array_equal(out[2], out[4])  # (the one-wave team kernel reproduces the wave kernel bit for bit)
+    assert not np.array_equal(out[2], out[4]) and not np.array_equal(out[2], out[3])  # (the one-wave team kernel reproduces the wave kernel bit for bit)
 
 
-def test_census_subset_within_gate():
+@pytest.mark.parametrize("variant", [0, 3])
+def test_census_subset_within_gate(variant):
     """160 committed census traces (config-2 draws and PT-ensemble solves, thin and thick films, TRPL and
     TRTS; tests/golden/make_census_subset.py): every one within 1e-6 of the converged oracle over the
-    4-decade window -- the regression guard of the tolerance policy."""
-    from metrotrpl_amd import batch
+    4-decade window -- the regression guard of the tolerance policy.  Through the default
+    kernel choice and through the two-solves-per-SIMD kernel (fp32-stored elimination blocks)."""
+    from metrotrpl_amd import _lib as L, batch
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "census_subset.npz"))
     idx = {n: i for i, n in enumerate(str(z["names"]).split(","))}
-    sig, status, stats = batch.solve_batch(z["states"], idx, z["units"], z["iniPar"], z["thickness"], 128, z["tSteps"],
-                                           meas=[str(m) for m in z["meas"]], return_stats=True)
+    ctx = L.default_context()
+    ctx.set_option("kernel_variant", variant)
+    try:
+        sig, status, stats = batch.solve_batch(z["states"], idx, z["units"], z["iniPar"], z["thickness"], 128, z["tSteps"],
+                                               meas=[str(m) for m in z["meas"]], return_stats=True)
+    finally:
+        ctx.set_option("kernel_variant", 0)
     assert np.all(status == 0)
     errs = np.zeros(len(sig))
     for k in range(len(sig)):

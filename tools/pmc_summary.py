@@ -21,12 +21,13 @@ for d in sys.argv[3:]:
             vals[c] = sum(v) / len(v)  # average per launch
 fetch, write = vals.get("FETCH_SIZE"), vals.get("WRITE_SIZE")
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, --kernel-trace only) on "
-                 "`python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --streams 1 --sort-by-cost 0` (one launch at a time on the device); kernel " + kern + ", average per launch (1024 solves)",
+                 "`python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --streams 1 --sort-by-cost 0 [--batch 2048 --opt kernel_variant=3 for solve_kernel_wave2]` (one launch at a time on the device); kernel " + kern + ", average per launch",
+       "solves_per_launch": 2048 if "wave2" in kern else 1024,
        "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
        "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE reports 1/2 of a wide coalesced read on gfx950 -> doubled; "
                      "WRITE_SIZE exact; both in KiB.  Reads here are small descriptor/time-grid loads, so the factor is an upper bound.",
        "solve_kernel_bytes_per_launch": (2 * fetch + write) * 1024 if fetch is not None and write is not None else None,
-       "expected_compulsory_bytes_per_launch": 1024 * (280 + 8 * 1001 + 4 + 32) + 8 * 1001,
+       "expected_compulsory_bytes_per_solve": (280 + 8 * 1001 + 4 + 32),
        "sq_counters_per_launch": {k: v for k, v in vals.items() if k.startswith("SQ_")}}
 sq = res["sq_counters_per_launch"]
 if "SQ_WAVES" in sq:
@@ -40,7 +41,7 @@ if "SQ_WAVES" in sq:
                       "scalar_active_fraction_of_wave_cycles": frac("SQ_ACTIVE_INST_SCA"),
                       "parked_on_waitcnt_fraction_of_wave_cycles": frac("SQ_WAIT_ANY"),
                       "issue_stall_fraction_of_wave_cycles": frac("SQ_WAIT_INST_ANY"),
-                      "occupancy_waves_per_simd": 1,
+                      "occupancy_waves_per_simd": 2 if "wave2" in kern else 1,
                       "wave_cycles_per_solve(quad-cycles*4)": 4 * sq.get("SQ_WAVE_CYCLES", 0) / w}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
