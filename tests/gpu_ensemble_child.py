@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--rng-mode", default="stream")
     ap.add_argument("--prefetch", type=int, default=0)
     ap.add_argument("--groups", type=int, default=1)
+    ap.add_argument("--kernel-variant", type=int, default=0)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     import torch
@@ -34,7 +35,8 @@ def main():
     if a.dist:
         dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{a.port}", rank=0, world_size=1, device_id=dev)
     torch.cuda.set_device(0)
-    from metrotrpl_amd import pt, pt_bench
+    from metrotrpl_amd import _lib as L, pt, pt_bench
+    L.default_context(0).set_option("kernel_variant", a.kernel_variant)
     irf_raw = np.load(os.path.join(REPO, "tests", "golden", "irf.npz"))["irf745_raw"]
     S = pt_bench.setup(a.chains, dev, 0, irf_raw=irf_raw, parts=a.parts, sort_by_cost=bool(a.sort), split_min=0,
                        sort_min=0, force_min_y=bool(a.force_min_y), groups=a.groups)
