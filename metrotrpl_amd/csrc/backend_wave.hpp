@@ -283,6 +283,9 @@ struct WaveBackendT {
 
 using WaveBackend = WaveBackendT<false>;
 
+// CT: the integrator options are the shipped ones and compiled in (the host checks) -- none of them sits in
+// (spilled) scalar registers.
+template <bool CT>
 __global__ __launch_bounds__(64, 1) void solve_kernel_wave(const mtrpl_solve_desc *__restrict__ descs,
                                                             const double *__restrict__ ini,
                                                             const double *__restrict__ tsteps,
@@ -294,10 +297,14 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_wave(const mtrpl_solve_des
     if (sidx >= B) return;
     __shared__ double2 fac_lds[kFactorLdsBytes / 16];
     WaveBackend bk(threadIdx.x & 63, fac_lds);
-    integrate(bk, descs[sidx], ini, tsteps, out, status, stats, sidx, tune, clk0_);
+    if (CT)
+        integrate(bk, descs[sidx], ini, tsteps, out, status, stats, sidx, DefaultTune{}, clk0_);
+    else
+        integrate(bk, descs[sidx], ini, tsteps, out, status, stats, sidx, tune, clk0_);
 }
 
 // Two solves per SIMD: fp32-stored blocks (17 KB of LDS per wave, 8 waves per CU) and a 256-register budget.
+template <bool CT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void solve_kernel_wave2(
     const mtrpl_solve_desc *__restrict__ descs, const double *__restrict__ ini, const double *__restrict__ tsteps,
     double *__restrict__ out, int32_t *__restrict__ status, int32_t *__restrict__ stats, int64_t B, SolveTuning tune)
@@ -307,7 +314,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (sidx >= B) return;
     __shared__ float4 fac_lds[kFactorLdsBytesF32 / 16];
     WaveBackendT<true> bk(threadIdx.x & 63, fac_lds);
-    integrate(bk, descs[sidx], ini, tsteps, out, status, stats, sidx, tune, clk0_);
+    if (CT)
+        integrate(bk, descs[sidx], ini, tsteps, out, status, stats, sidx, DefaultTune{}, clk0_);
+    else
+        integrate(bk, descs[sidx], ini, tsteps, out, status, stats, sidx, tune, clk0_);
 }
 
 }  // namespace mtrpl

@@ -33,7 +33,7 @@ struct Slab {
 struct mtrpl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    SolveTuning tune{0.1, 3e-9, 3e-10, 3e-11, 0.0, 1e-4, 1e-8, 2000000, 0.1, 8, 4.0, 3.0, 1, 1e-11, 0.5, 16.0, 1.2, 80, 1.2, 1.0, 1.0, 1.0, 10.0, 0.5};
+    SolveTuning tune = DefaultTune::make();
     std::string err;
     // IRF tables resident on the device (mtrpl_irf_tables_upload)
     double *d_irf_tab = nullptr;
@@ -414,6 +414,16 @@ const OptI kOptI[] = {
     {"max_steps", &SolveTuning::max_steps}, {"rate_max_age", &SolveTuning::rate_max_age},
     {"honor_hmax", &SolveTuning::honor_hmax}, {"nq_rej_memory", &SolveTuning::nq_rej_memory},
 };
+// every option still at its shipped value: the kernel instantiation with the options compiled in may run
+bool default_tune(const SolveTuning &t)
+{
+    const SolveTuning d = DefaultTune::make();
+    for (const OptD &o : kOptD)
+        if (t.*(o.m) != d.*(o.m)) return false;
+    for (const OptI &o : kOptI)
+        if (t.*(o.m) != d.*(o.m)) return false;
+    return true;
+}
 }  // namespace
 
 int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value)
@@ -498,10 +508,17 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
         else { if (variant == 4) MTRPL_PAIR(2, 3, 1); else MTRPL_PAIR(2, 0, 2); }
 #undef MTRPL_PAIR
     } else if (variant == 3) {
-        hipLaunchKernelGGL(solve_kernel_wave2, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
+        if (default_tune(ctx->tune))
+            hipLaunchKernelGGL(solve_kernel_wave2<true>, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
+                               d_status, d_stats, B, ctx->tune);
+        else
+            hipLaunchKernelGGL(solve_kernel_wave2<false>, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
+                               d_status, d_stats, B, ctx->tune);
+    } else if (default_tune(ctx->tune)) {
+        hipLaunchKernelGGL(solve_kernel_wave<true>, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
                            d_status, d_stats, B, ctx->tune);
     } else {
-        hipLaunchKernelGGL(solve_kernel_wave, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
+        hipLaunchKernelGGL(solve_kernel_wave<false>, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
                            d_status, d_stats, B, ctx->tune);
     }
     HIP_TRY(ctx, hipGetLastError());

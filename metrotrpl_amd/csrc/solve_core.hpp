@@ -85,6 +85,29 @@ struct SolveTuning {
     double early_frac;
 };
 
+// The shipped settings as compile-time constants: a kernel instantiated on this type instead of on the
+// run-time struct keeps none of them in (spilled) scalar registers.  Single source of the defaults.
+struct DefaultTune {
+    static constexpr double rtol_scale = 0.1, rtol_cap = 3e-9, rtol_floor = 3e-10, rtol_min = 3e-11, rtol_force = 0.0;
+    static constexpr double atol_rel = 1e-4, atol_rel_np = 1e-8;
+    static constexpr int max_steps = 2000000;
+    static constexpr double newton_tol = 0.1;
+    static constexpr int rate_max_age = 8;
+    static constexpr double rate_first_safety = 4.0, e_weight = 3.0;
+    static constexpr int honor_hmax = 1;
+    static constexpr double hmax_deep = 1e-11, trts_rtol_factor = 0.5, amp_ref = 16.0, nq_deadband_hi = 1.2;
+    static constexpr int nq_rej_memory = 80;
+    static constexpr double nq_rej_growth = 1.2, nq_bias_same = 1.0, nq_bias_down = 1.0, nq_bias_up = 1.0;
+    static constexpr double early_factor = 10.0, early_frac = 0.5;
+    static SolveTuning make()
+    {
+        return SolveTuning{rtol_scale, rtol_cap, rtol_floor, rtol_min, rtol_force, atol_rel, atol_rel_np, max_steps,
+                           newton_tol, rate_max_age, rate_first_safety, e_weight, honor_hmax, hmax_deep, trts_rtol_factor,
+                           amp_ref, nq_deadband_hi, nq_rej_memory, nq_rej_growth, nq_bias_same, nq_bias_down, nq_bias_up,
+                           early_factor, early_frac};
+    }
+};
+
 // ODEPACK cfode, meth = 2: l-vector and error-test constants of the fixed-step BDF of order Q
 struct NqTable {
     double el[6][6];   // el[q][j], q = 1..5
@@ -208,11 +231,11 @@ struct Emitter {
     }
 };
 
-template <class BK>
+template <class BK, class TUNE>  // TUNE: SolveTuning (run-time options) or DefaultTune (the shipped ones, constants)
 __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const double *__restrict__ ini,
                                  const double *__restrict__ tsteps, double *__restrict__ out,
                                  int32_t *__restrict__ status, int32_t *__restrict__ stats, int64_t sidx,
-                                 const SolveTuning &tune, unsigned long long clk0_)
+                                 const TUNE &tune, unsigned long long clk0_)
 {
 #ifdef MTRPL_SCHED
     const unsigned long long sched_t0_ = __builtin_amdgcn_s_memrealtime();
