@@ -14,14 +14,14 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc${T}_fetc
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc${T}_write -- $BENCH1 > $O/pmc${T}2.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc${T}_sq -- $BENCH1 > $O/pmc${T}3.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/pmc${T}_sq2 -- $BENCH1 > $O/pmc${T}4.log 2>&1
-python tools/pmc_summary.py "solve_kernel_wave(" $O/hbm_traffic_$T.json $O/pmc${T}_fetch $O/pmc${T}_write $O/pmc${T}_sq $O/pmc${T}_sq2 | tail -12
+python tools/pmc_summary.py "solve_kernel_wave<" $O/hbm_traffic_$T.json $O/pmc${T}_fetch $O/pmc${T}_write $O/pmc${T}_sq $O/pmc${T}_sq2 | tail -12
 # the same counters for the two-solves-per-SIMD kernel of the timed region (one 2048-solve launch at a time)
 BENCH2="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --streams 1 --sort-by-cost 0 --batch 2048 --opt kernel_variant=3"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc${T}w2_fetch -- $BENCH2 > $O/pmc${T}w2_1.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc${T}w2_write -- $BENCH2 > $O/pmc${T}w2_2.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc${T}w2_sq -- $BENCH2 > $O/pmc${T}w2_3.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/pmc${T}w2_sq2 -- $BENCH2 > $O/pmc${T}w2_4.log 2>&1
-python tools/pmc_summary.py "solve_kernel_wave2(" $O/hbm_traffic_wave2_$T.json $O/pmc${T}w2_fetch $O/pmc${T}w2_write $O/pmc${T}w2_sq $O/pmc${T}w2_sq2 | tail -12
+python tools/pmc_summary.py "solve_kernel_wave2<" $O/hbm_traffic_wave2_$T.json $O/pmc${T}w2_fetch $O/pmc${T}w2_write $O/pmc${T}w2_sq $O/pmc${T}w2_sq2 | tail -12
 timeout -k 10 300 python bench.py --workload pt --chains 512 --steps 20 --warmup 10 > $O/${T}_bench_pt512_1gpu.json 2>> $O/${T}_bench.err
 timeout -k 10 300 python bench.py --workload pt --chains 64 --steps 40 --warmup 10 --no-cpu-baseline > $O/${T}_bench_pt64_1gpu.json 2>> $O/${T}_bench.err
 timeout -k 10 300 python bench.py --workload pt --chains 64 --steps 40 --warmup 10 --no-cpu-baseline --groups 1 > $O/${T}_bench_pt64_1gpu_groups1.json 2>> $O/${T}_bench.err
