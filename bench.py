@@ -346,6 +346,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, **pmc, "kernel": kern_name,
                          "kernel_ms": kern_ms, "launches_in_flight": S, "algorithmic_bytes_per_solve": A,
+                         "device": {"achieved": A * B / (dt / a.steps) / 1e9, "frac": A * B / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
+                                    "note": "the same bytes per launch over the time per step: what the device does with "
+                                            "launches_in_flight launches sharing it (achieved / frac above are per launch)"},
                          "single_stream": None if kern1_ms is None else {
                              "kernel_ms": kern1_ms, "achieved": A * B / (kern1_ms * 1e-3) / 1e9,
                              "frac": A * B / (kern1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
