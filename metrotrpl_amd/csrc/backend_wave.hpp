@@ -54,7 +54,8 @@ struct WaveBackendT {
     __device__ inline void put(int blk, const M2 &m) const
     {
         if (F32BLK) {
-            static_cast<float4 *>(lds)[blk * 64 + lane] = float4{(float)m.a, (float)m.b, (float)m.c, (float)m.d};
+            // stored by columns (a, c | b, d): a block times a vector is then two packed fp32 FMAs
+            static_cast<float4 *>(lds)[blk * 64 + lane] = float4{(float)m.a, (float)m.c, (float)m.b, (float)m.d};
         } else {
             static_cast<double2 *>(lds)[(blk * 2 + 0) * 64 + lane] = double2{m.a, m.b};
             static_cast<double2 *>(lds)[(blk * 2 + 1) * 64 + lane] = double2{m.c, m.d};
@@ -70,7 +71,7 @@ struct WaveBackendT {
         const char *base = static_cast<const char *>(lds) + lds_off;
         if (F32BLK) {
             const float4 q = *reinterpret_cast<const float4 *>(base + blk * 1024);
-            return M2{(double)q.x, (double)q.y, (double)q.z, (double)q.w};
+            return M2{(double)q.x, (double)q.z, (double)q.y, (double)q.w};
         }
         const double2 u = *reinterpret_cast<const double2 *>(base + (blk * 2 + 0) * 1024);
         const double2 v = *reinterpret_cast<const double2 *>(base + (blk * 2 + 1) * 1024);
@@ -228,9 +229,88 @@ struct WaveBackendT {
         Bfin = minv(Bk);
     }
 
+    // ---- the re-solve with fp32-stored blocks: exchanged vectors and block products in packed fp32 ----
+    // Everything the blocks touch is rounded to fp32 anyway, so the vectors travel as fp32 (half the dwords per
+    // exchange) and a block times a vector is two v_pk_fma_f32; the running right-hand side, the E-elimination
+    // and the field back-substitution stay fp64.  Still an approximate inverse applied to an fp64 residual.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    struct PB { v2f ac, bd; };
+    __device__ inline PB get_pb(int blk)
+    {
+        asm volatile("" : "+v"(lds_off));
+        const float4 q = *reinterpret_cast<const float4 *>(static_cast<const char *>(lds) + lds_off + blk * 1024);
+        return PB{v2f{q.x, q.y}, v2f{q.z, q.w}};
+    }
+    static __device__ inline v2f pb_acc(const PB &B, v2f r, v2f acc) { return B.bd * v2f(r.y) + (B.ac * v2f(r.x) + acc); }
+    static __device__ inline v2f narrow(const V2 &v) { return v2f{(float)v.x, (float)v.y}; }
+
+    __device__ inline void apply_f32(const double (&b)[V], double (&x)[V])
+    {
+        const PB cr_al = get_pb(CR_AL), cr_ga = get_pb(CR_GA);
+        PB al = get_pb(PAL0), ga = get_pb(PGA0);
+        V2 wb[3];
+        wb[0] = V2{w[0][0] * b[4], w[0][1] * b[4]};
+        wb[1] = V2{w[1][0] * b[5], w[1][1] * b[5]};
+        wb[2] = vnext(wb[0]);
+        V2 r[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const V2 nxt = wb[q + 1];
+            r[q] = V2{b[q] + cd * (nxt.x - wb[q].x), b[2 + q] - cd * (nxt.y - wb[q].y)};
+        }
+        const v2f r0 = narrow(r[0]);
+        const v2f r0_up{from_next(r0.x), from_next(r0.y)};
+        const v2f t = pb_acc(cr_ga, r0_up, pb_acc(cr_al, r0, v2f(0.0f)));
+        V2 rk{r[1].x - (double)t.x, r[1].y - (double)t.y};
+        PB b_inv = al, b_ia = al, b_ic = al;
+#pragma unroll
+        for (int lv = 0; lv < 6; ++lv) {
+            const int s = 1 << lv;
+            PB al_n = al, ga_n = ga;
+            if (lv < 5) {
+                al_n = get_pb(PAL0 + lv + 1);
+                ga_n = get_pb(PGA0 + lv + 1);
+            } else {
+                b_inv = get_pb(BINV_E);
+                b_ia = get_pb(BIA_E);
+                b_ic = get_pb(BIC_E);
+            }
+            const v2f rf = narrow(rk);
+            v2f rm, rp;
+            if (lv == 0) {
+                rm = v2f{from_prev(rf.x), from_prev(rf.y)};
+                rp = v2f{from_next(rf.x), from_next(rf.y)};
+            } else if (lv == 5) {
+                float mx, px, my, py;
+                swap32(rf.x, mx, px);
+                swap32(rf.y, my, py);
+                rm = v2f{mx, my};
+                rp = v2f{px, py};
+            } else {
+                rm = v2f{shf(rf.x, (lane - s) & 63), shf(rf.y, (lane - s) & 63)};
+                rp = v2f{shf(rf.x, (lane + s) & 63), shf(rf.y, (lane + s) & 63)};
+            }
+            const v2f u = pb_acc(ga, rp, pb_acc(al, rm, v2f(0.0f)));
+            rk = V2{rk.x - (double)u.x, rk.y - (double)u.y};
+            al = al_n;
+            ga = ga_n;
+        }
+        const V2 xk = mvec(Bfin, rk);
+        const V2 xk_prev = vprev(xk);
+        const v2f se = pb_acc(b_inv, r0, v2f(0.0f)) - pb_acc(b_ic, narrow(xk), pb_acc(b_ia, narrow(xk_prev), v2f(0.0f)));
+        const V2 xe{(double)se.x, (double)se.y};
+        x[0] = xe.x; x[1] = xk.x; x[2] = xe.y; x[3] = xk.y;
+        x[4] = b[4] * mvv[0] - (eco[0][0] * xk_prev.x + eco[0][1] * xe.x + eco[0][2] * xk_prev.y + eco[0][3] * xe.y);
+        x[5] = b[5] * mvv[1] - (eco[1][0] * xe.x + eco[1][1] * xk.x + eco[1][2] * xe.y + eco[1][3] * xk.y);
+    }
+
     // x = M^{-1} b; b, x in lane layout [N0,N1,P0,P1,E0,E1]
     __device__ inline void apply(const double (&b)[V], double (&x)[V])
     {
+        if constexpr (F32BLK) {
+            apply_f32(b, x);
+            return;
+        }
         // E-elimination right-hand side
         V2 wb[3];
         wb[0] = V2{w[0][0] * b[4], w[0][1] * b[4]};
