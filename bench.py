@@ -322,7 +322,8 @@ def main():
         A = algorithmic_bytes_per_solve(c["nx"], nt)
         achieved = A * B / (kern_ms * 1e-3) / 1e9
         from metrotrpl_amd.pt_bench import pmc_fields
-        kern_name = "solve_kernel_wave2" if (S > 1 and not user_variant) else "solve_kernel_wave"
+        kern_name = "solve_kernel_wave2" if (S > 1 and not user_variant) or (not user_variant and B >= 1025) else \
+            ("solve_kernel_wave1" if not user_variant else "as set by --opt")
         pmc = pmc_fields(B, kern_name)
         line = {
             "metric": "trpl_forward_solves_per_sec", "value": world * B * a.steps / dt, "unit": "solves/s",

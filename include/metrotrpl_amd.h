@@ -124,15 +124,19 @@ const char *mtrpl_version(void);
  *                                     early_frac * (first requested sample time)
  *   honor_hmax                        1: desc.hmax is the maximum step (the reference's max_step)
  *   max_steps                         a solve that needs more stops early (status 1, tail zero-filled)
- *   kernel_variant                    std model, nx <= 128: 0 automatic; 2 wave kernel (one wavefront per solve, one
- *                                     solve per SIMD: the shortest solve); 3 the same with the elimination blocks
- *                                     stored as fp32 and two solves per SIMD (each ~12 % slower, 1.3-1.4x the solves
- *                                     per second when more solves than SIMDs are in flight; results agree with 2
- *                                     inside the accuracy gate, not bitwise); 4 / 5 wave-pair kernel (two wavefronts
- *                                     per solve, blocks in registers / in LDS); 1 team kernel (the one traps and
- *                                     nx > 128 use).  Automatic: 3 for launches of at least two_per_simd_min_batch
- *                                     solves (default 1025: more solves than SIMDs on this device; set it to 1 when
- *                                     several smaller launches are in flight on different streams), else 2;
+ *   kernel_variant                    std model, nx <= 128: 0 automatic -- the wave kernel (one wavefront per solve)
+ *                                     with the elimination blocks stored as fp32 and the re-solve in packed fp32 on
+ *                                     an fp64 right-hand side (an approximate inverse applied to the fp64 residual
+ *                                     of the simplified Newton iteration: same converged corrector, same accuracy
+ *                                     gates), built twice: one solve per SIMD (6: the shortest solve) for launches
+ *                                     of fewer than two_per_simd_min_batch solves, two per SIMD (3: 1.3-1.5x the
+ *                                     solves per second when more solves than SIMDs are in flight) from there on
+ *                                     (default 1025 = more solves than SIMDs on this device; set it to 1 when several
+ *                                     smaller launches are in flight on different streams); a solve gives the same
+ *                                     result on either build.  2: the wave kernel with fp64 blocks and an fp64
+ *                                     re-solve (the exact linear algebra; agrees with the default inside the
+ *                                     accuracy gate, not bitwise); 4 / 5 wave-pair kernel (two wavefronts per solve,
+ *                                     blocks in registers / in LDS); 1 team kernel (the one traps and nx > 128 use);
  *                                     pair_max_batch: launches of at most this many solves use 4 (default 0)
  *   precision                         64 (product) | 32 (fp32 instantiation of the team kernel: precision sweep only) */
 int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value);

@@ -400,4 +400,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         integrate(bk, descs[sidx], ini, tsteps, out, status, stats, sidx, tune, clk0_);
 }
 
+// The same backend with the whole register file: one solve per SIMD, the shortest solve (the packed-fp32 re-solve
+// makes it faster than the fp64-block kernel).  Same arithmetic as solve_kernel_wave2: a solve gives the same
+// result on either.
+template <bool CT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void solve_kernel_wave1(
+    const mtrpl_solve_desc *__restrict__ descs, const double *__restrict__ ini, const double *__restrict__ tsteps,
+    double *__restrict__ out, int32_t *__restrict__ status, int32_t *__restrict__ stats, int64_t B, SolveTuning tune)
+{
+    const int64_t sidx = blockIdx.x;
+    const unsigned long long clk0_ = __builtin_amdgcn_s_memtime();
+    if (sidx >= B) return;
+    __shared__ float4 fac_lds[kFactorLdsBytesF32 / 16];
+    WaveBackendT<true> bk(threadIdx.x & 63, fac_lds);
+    if (CT)
+        integrate(bk, descs[sidx], ini, tsteps, out, status, stats, sidx, DefaultTune{}, clk0_);
+    else
+        integrate(bk, descs[sidx], ini, tsteps, out, status, stats, sidx, tune, clk0_);
+}
+
 }  // namespace mtrpl

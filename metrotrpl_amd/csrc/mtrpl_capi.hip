@@ -49,7 +49,8 @@ struct mtrpl_ctx {
     int precision = 64;      // 64: fp64 (the product); 32: the fp32 build of the team kernel (precision sweep only)
     size_t like_lds_attr = 64 * 1024;  // dynamic-LDS limit the likelihood kernel has been raised to
     int two_per_simd_min_batch = 1025;  // kernel_variant 0: launches of at least this many std / nx <= 128 solves use
-                                        // the two-solves-per-SIMD wave kernel (more than one solve per SIMD anyway)
+                                        // the two-solves-per-SIMD build of the wave kernel (more than one solve per
+                                        // SIMD anyway), smaller ones the one-per-SIMD build: same results
     int pair_max_batch = 0;  // kernel_variant 0: launches up to this many solves use the wave-pair kernel (0: never --
                              // measured: its exchanges cost what the halved per-lane work saves)
 };
@@ -436,8 +437,8 @@ int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value)
         if (k == o.key) { ctx->tune.*(o.m) = (int)value; return MTRPL_OK; }
     if (k == "kernel_variant") {
         const int v = (int)value;
-        if (v != 0 && v != 1 && v != 2 && v != 3 && v != 4 && v != 5)
-            return bad(ctx, MTRPL_ERR_BAD_ARG, "kernel_variant must be 0 (auto), 1 (team), 2 (wave), 3 (wave, two per SIMD), 4 or 5 (wave pair)");
+        if (v != 0 && v != 1 && v != 2 && v != 3 && v != 4 && v != 5 && v != 6)
+            return bad(ctx, MTRPL_ERR_BAD_ARG, "kernel_variant must be 0 (auto), 1 (team), 2 (wave, fp64 blocks), 3 / 6 (wave, fp32 blocks, two / one per SIMD), 4 or 5 (wave pair)");
         ctx->kernel_variant = v;
     } else if (k == "pair_max_batch") {
         ctx->pair_max_batch = (int)value;
@@ -488,15 +489,25 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
         return MTRPL_OK;
     }
     // std model, nx <= 128: the register-resident backends.
-    //   wave (2):  one wave per solve, two nodes per lane, one solve per SIMD -- the shortest solve
-    //   wave (3):  the same with the elimination blocks stored as fp32 and a 256-register budget: two solves
-    //              per SIMD, each ~12 % slower alone, 1.3-1.4x the solves per second once the SIMDs are
-    //              over-subscribed (the second wave fills the issue slots the first leaves waiting on LDS)
-    //   pair (4):  two waves per solve, one node per lane, blocks in registers (opt-in: pair_max_batch)
-    //   pair (5):  the same with every block in LDS and a register budget for two waves per SIMD
+    //   wave1 (6): one wave per solve, two nodes per lane; elimination blocks stored as fp32, re-solve in packed
+    //              fp32 on an fp64 right-hand side; one solve per SIMD -- the shortest solve
+    //   wave2 (3): the same arithmetic on a 256-register budget: two solves per SIMD, 1.3-1.5x the solves per
+    //              second once the SIMDs are over-subscribed (the second wave fills the issue slots the first
+    //              leaves waiting)
+    //   wave  (2): fp64 blocks and an fp64 re-solve: the exact linear algebra, one solve per SIMD
+    //   pair  (4): two waves per solve, one node per lane, blocks in registers (opt-in: pair_max_batch)
+    //   pair  (5): the same with every block in LDS and a register budget for two waves per SIMD
     int variant = ctx->kernel_variant;
     if (variant == 0)
-        variant = (!traps && max_nx <= 128 && B <= ctx->pair_max_batch) ? 4 : ((B >= ctx->two_per_simd_min_batch) ? 3 : 2);
+        variant = (!traps && max_nx <= 128 && B <= ctx->pair_max_batch) ? 4 : ((B >= ctx->two_per_simd_min_batch) ? 3 : 6);
+    const bool ct = default_tune(ctx->tune);
+#define MTRPL_WAVE(KERNEL)                                                                                            \
+    do {                                                                                                              \
+        if (ct) hipLaunchKernelGGL(KERNEL<true>, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,  \
+                                   d_status, d_stats, B, ctx->tune);                                                  \
+        else hipLaunchKernelGGL(KERNEL<false>, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,    \
+                                d_status, d_stats, B, ctx->tune);                                                     \
+    } while (0)
     if (traps || max_nx > 128 || variant == 1) {
         const int rc = launch_team_any<double>(ctx, s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, max_nx, traps);
         if (rc != MTRPL_OK) return rc;
@@ -508,19 +519,13 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
         else { if (variant == 4) MTRPL_PAIR(2, 3, 1); else MTRPL_PAIR(2, 0, 2); }
 #undef MTRPL_PAIR
     } else if (variant == 3) {
-        if (default_tune(ctx->tune))
-            hipLaunchKernelGGL(solve_kernel_wave2<true>, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
-                               d_status, d_stats, B, ctx->tune);
-        else
-            hipLaunchKernelGGL(solve_kernel_wave2<false>, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
-                               d_status, d_stats, B, ctx->tune);
-    } else if (default_tune(ctx->tune)) {
-        hipLaunchKernelGGL(solve_kernel_wave<true>, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
-                           d_status, d_stats, B, ctx->tune);
+        MTRPL_WAVE(solve_kernel_wave2);
+    } else if (variant == 6) {
+        MTRPL_WAVE(solve_kernel_wave1);
     } else {
-        hipLaunchKernelGGL(solve_kernel_wave<false>, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,
-                           d_status, d_stats, B, ctx->tune);
+        MTRPL_WAVE(solve_kernel_wave);
     }
+#undef MTRPL_WAVE
     HIP_TRY(ctx, hipGetLastError());
     return MTRPL_OK;
 }
@@ -628,7 +633,7 @@ int mtrpl_newton_probe(mtrpl_ctx *ctx, int64_t B, int32_t nx, const double *par,
         else if (nx <= 64) hipLaunchKernelGGL((newton_probe_kernel_pair<1, 0>), dim3((unsigned)B), dim3(64), MTRPL_NP_ARGS);
         else if (variant == 4) hipLaunchKernelGGL((newton_probe_kernel_pair<2, 3>), dim3((unsigned)B), dim3(128), MTRPL_NP_ARGS);
         else hipLaunchKernelGGL((newton_probe_kernel_pair<2, 0>), dim3((unsigned)B), dim3(128), MTRPL_NP_ARGS);
-    } else if (variant == 3) {
+    } else if (variant == 3 || variant == 6 || variant == 0) {
         hipLaunchKernelGGL(newton_probe_kernel_wave<true>, dim3((unsigned)B), dim3(64), MTRPL_NP_ARGS);
     } else {
         hipLaunchKernelGGL(newton_probe_kernel_wave<false>, dim3((unsigned)B), dim3(64), MTRPL_NP_ARGS);

@@ -159,7 +159,7 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
         n_solve = [n for *_, n in timing]
         kern_ms = float(np.mean(t_solve))
         # launches of more than 1024 solves go to the two-solves-per-SIMD form of the wave kernel (include/metrotrpl_amd.h)
-        kern_name = "solve_kernel_wave2" if float(np.mean(n_solve)) >= 1025 else "solve_kernel_wave"
+        kern_name = "solve_kernel_wave2" if float(np.mean(n_solve)) >= 1025 else "solve_kernel_wave1"
         achieved = A * float(np.mean(n_solve)) / (kern_ms * 1e-3) / 1e9
         line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS, "kernel": kern_name, "kernel_ms": kern_ms,
@@ -185,7 +185,7 @@ def algorithmic_bytes(nx, nt, model="std", irf_nk=0):
     return a
 
 
-def pmc_fields(solves_per_launch=1024, kernel="solve_kernel_wave"):
+def pmc_fields(solves_per_launch=1024, kernel="solve_kernel_wave1"):
     """Counter-derived figures of the solve kernel from the committed rocprofv3 --pmc summaries (they are not
     measured in this run; traffic_source says where they come from).  The traffic is per solve -- descriptor
     in, samples out -- and is scaled from the profiled launch to `solves_per_launch`."""

@@ -31,7 +31,7 @@ def per_decade(sig, ref):
     return out
 
 
-@pytest.mark.parametrize("variant", [0, 3])  # the default kernel choice | two solves per SIMD, fp32-stored blocks
+@pytest.mark.parametrize("variant", [0, 3, 2])  # default (fp32-stored blocks, one per SIMD here) | two per SIMD | fp64 blocks
 @pytest.mark.parametrize("part", ["config2", "config3"])
 def test_every_decade_of_every_trace(part, variant):
     from metrotrpl_amd import _lib as L, batch

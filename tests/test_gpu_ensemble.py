@@ -81,12 +81,10 @@ def test_config3_ensemble_through_rccl_and_two_streams(tmp_path):
 def test_prefetched_ensemble_walks_the_same_chain(tmp_path):
     """Two iterations per launch (192 states x 6 solves, both outcomes of the first evaluated ahead,
     pt.PTEnsemble.iterate2) through RCCL == one iteration per launch, bit for bit, on the real evaluator."""
-    # (the solve kernel pinned: left to itself the library runs launches of more than 1024 solves two per SIMD
-    # with fp32-stored elimination blocks -- equally converged, not bitwise the same)
-    one = _child(tmp_path, "one", dist=0, parts=1, sort=0, rng_mode="counter", prefetch=0, iters=12, temper_freq=4,
-                 kernel_variant=2)
+    # (384-solve launches run one solve per SIMD, 1152-solve launches two per SIMD: the same arithmetic)
+    one = _child(tmp_path, "one", dist=0, parts=1, sort=0, rng_mode="counter", prefetch=0, iters=12, temper_freq=4)
     two = _child(tmp_path, "two", dist=1, parts=1, sort=1, rng_mode="counter", prefetch=1, iters=12, temper_freq=4,
-                 port=29619, kernel_variant=2)
+                 port=29619)
     assert list(one["calls"]) == [64] * 12 and list(two["calls"]) == [192] * 6
     assert str(two["backend"]) == "nccl" and bool(two["ordered"])
     for key in ("states", "logll", "table", "swap_attempts", "swap_accepts", "n_acc"):
@@ -94,12 +92,13 @@ def test_prefetched_ensemble_walks_the_same_chain(tmp_path):
     assert int(one["n_acc"]) > 0 and one["swap_attempts"].sum() == 3 * 63
     # ... and cut into two chain groups, each with its own engine and HIP stream, launches overlapping
     grp = _child(tmp_path, "grp", dist=1, parts=1, sort=1, rng_mode="counter", prefetch=1, iters=12, temper_freq=4,
-                 groups=2, port=29620, kernel_variant=2)
+                 groups=2, port=29620)
     assert list(grp["calls"]) == [96] * 12 and str(grp["backend"]) == "nccl"
     for key in ("states", "logll", "table", "swap_attempts", "swap_accepts", "n_acc"):
         np.testing.assert_array_equal(one[key], grp[key], err_msg=key)
-    # left to itself (1152-solve launches on the two-per-SIMD kernel): the same decisions, log-likelihoods to 1e-7
-    auto = _child(tmp_path, "auto", dist=0, parts=1, sort=1, rng_mode="counter", prefetch=1, iters=12, temper_freq=4)
-    np.testing.assert_array_equal(one["states"], auto["states"])
-    np.testing.assert_array_equal(one["swap_accepts"], auto["swap_accepts"])
-    np.testing.assert_allclose(one["logll"], auto["logll"], rtol=1e-7)
+    # the fp64-block kernel walks the same chain: the same decisions, log-likelihoods to 1e-7
+    f64 = _child(tmp_path, "f64", dist=0, parts=1, sort=1, rng_mode="counter", prefetch=1, iters=12, temper_freq=4,
+                 kernel_variant=2)
+    np.testing.assert_array_equal(one["states"], f64["states"])
+    np.testing.assert_array_equal(one["swap_accepts"], f64["swap_accepts"])
+    np.testing.assert_allclose(one["logll"], f64["logll"], rtol=1e-7)

@@ -106,7 +106,8 @@ def test_newton_linear_solver():
                 b[2 * nx] = 0.0
                 b[-1] = 0.0
                 x_ref = np.linalg.solve(M, b)
-                # one wave | one wave, blocks stored as fp32 | wave pair, blocks in registers | wave pair, blocks in LDS
+                # one wave, fp64 blocks | one wave, fp32-stored blocks + packed fp32 re-solve (the default) | wave pair,
+                # blocks in registers | wave pair, blocks in LDS
                 for variant in (2, 3, 4, 5):
                     ctx.set_option("kernel_variant", variant)
                     try:
@@ -115,8 +116,9 @@ def test_newton_linear_solver():
                         ctx.set_option("kernel_variant", 0)
                     res = np.linalg.norm(M @ x - b) / np.linalg.norm(b)
                     if variant == 3:
-                        # the blocks are rounded to fp32 on their way into LDS: an approximate inverse, good for a
-                        # contraction of the simplified Newton iteration by three orders of magnitude per sweep
+                        # blocks rounded to fp32 on their way into LDS, exchanged vectors and block products in fp32:
+                        # an approximate inverse, good for a contraction of the simplified Newton iteration by three
+                        # orders of magnitude per sweep
                         assert res < 1e-3, (variant, nx, k, c, res)
                         worst_f32 = max(worst_f32, res)
                         continue
@@ -266,16 +268,16 @@ def test_hard_cases_tauP_much_larger_than_tauN():
 
 
 def test_every_backend_lands_on_the_converged_traces():
-    """kernel_variant 2 (one wave per solve), 3 (the same, elimination blocks stored as fp32, two solves per SIMD),
-    4 / 5 (wave pair: SPIKE interface between the waves, blocks in registers / in LDS) and 1 (team kernel) are
-    different distributions of the same integrator: all within the gate on the hard cases, and not one kernel
-    behind five switches."""
+    """kernel_variant 6 / 3 (one wave per solve, fp32-stored elimination blocks, one / two solves per SIMD: the
+    default pair), 2 (fp64 blocks), 4 / 5 (wave pair: SPIKE interface between the waves, blocks in registers / in
+    LDS) and 1 (team kernel) are different distributions of the same integrator: all within the gate on the hard
+    cases, and not one kernel behind six switches.  The two builds of the default kernel give the same bits."""
     from metrotrpl_amd import _lib as L, batch
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "hard_cases.npz"))
     idx = {n: i for i, n in enumerate(str(z["names"]).split(","))}
     ctx = L.default_context()
     out = {}
-    variants = (2, 3, 4, 5, 1)
+    variants = (6, 3, 2, 4, 5, 1)
     try:
         for variant in variants:
             ctx.set_option("kernel_variant", variant)
@@ -291,14 +293,16 @@ def test_every_backend_lands_on_the_converged_traces():
         for variant in variants:
             assert np.max(np.abs(out[variant][k][m] - ref[m]) / np.abs(ref[m])) <= 1e-6, (variant, k)
     assert not np.array_equal(out[2], out[4]) and not np.array_equal(out[2], out[3])  # (the one-wave team kernel reproduces the wave kernel bit for bit)
+    np.testing.assert_array_equal(out[6], out[3])  # one or two solves per SIMD: the same arithmetic
 
 
-@pytest.mark.parametrize("variant", [0, 3])
+@pytest.mark.parametrize("variant", [0, 3, 2])
 def test_census_subset_within_gate(variant):
     """160 committed census traces (config-2 draws and PT-ensemble solves, thin and thick films, TRPL and
     TRTS; tests/golden/make_census_subset.py): every one within 1e-6 of the converged oracle over the
     4-decade window -- the regression guard of the tolerance policy.  Through the default
-    kernel choice and through the two-solves-per-SIMD kernel (fp32-stored elimination blocks)."""
+    kernel choice (fp32-stored elimination blocks, one solve per SIMD at this size), its two-per-SIMD build, and the
+    fp64-block kernel."""
     from metrotrpl_amd import _lib as L, batch
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "census_subset.npz"))
     idx = {n: i for i, n in enumerate(str(z["names"]).split(","))}

@@ -14,7 +14,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc${T}_fetc
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc${T}_write -- $BENCH1 > $O/pmc${T}2.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc${T}_sq -- $BENCH1 > $O/pmc${T}3.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/pmc${T}_sq2 -- $BENCH1 > $O/pmc${T}4.log 2>&1
-python tools/pmc_summary.py "solve_kernel_wave<" $O/hbm_traffic_$T.json $O/pmc${T}_fetch $O/pmc${T}_write $O/pmc${T}_sq $O/pmc${T}_sq2 | tail -12
+python tools/pmc_summary.py "solve_kernel_wave1<" $O/hbm_traffic_$T.json $O/pmc${T}_fetch $O/pmc${T}_write $O/pmc${T}_sq $O/pmc${T}_sq2 | tail -12
 # the same counters for the two-solves-per-SIMD kernel of the timed region (one 2048-solve launch at a time)
 BENCH2="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --streams 1 --sort-by-cost 0 --batch 2048 --opt kernel_variant=3"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc${T}w2_fetch -- $BENCH2 > $O/pmc${T}w2_1.log 2>&1

@@ -1,5 +1,6 @@
-"""Agreement of the two-solves-per-SIMD kernel (fp32-stored elimination blocks) with the one-per-SIMD kernel over
-many config-2 draws: worst relative difference per decade of signal decay (dev tool).
+"""Agreement of the default wave kernel (fp32-stored elimination blocks, packed-fp32 re-solve; kernel_variant 3: its
+two-per-SIMD build) with the fp64-block wave kernel (2) over many config-2 draws: worst relative difference per
+decade of signal decay (dev tool).
 usage: python tools/variant_agreement.py [n_solves]"""
 import os
 import sys
