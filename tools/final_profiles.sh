@@ -28,7 +28,9 @@ timeout -k 10 300 python bench.py --workload pt --chains 64 --steps 40 --warmup 
 timeout -k 10 300 python bench.py --workload pt --chains 64 --steps 40 --warmup 10 --no-cpu-baseline --groups 1 --prefetch off > $O/${T}_bench_pt64_1gpu_plain.json 2>> $O/${T}_bench.err
 timeout -k 10 100 python bench.py --no-cpu-baseline --steps 24 --streams 1 --sort-by-cost 0 > $O/${T}_bench_streams1.json 2>> $O/${T}_bench.err
 timeout -k 10 100 python bench.py --no-cpu-baseline --steps 24 --streams 2 > $O/${T}_bench_streams2.json 2>> $O/${T}_bench.err
-timeout -k 10 100 python bench.py --no-cpu-baseline --steps 24 --streams 3 --opt kernel_variant=2 > $O/${T}_bench_streams3_one_per_simd.json 2>> $O/${T}_bench.err
+timeout -k 10 100 python bench.py --no-cpu-baseline --steps 24 --streams 3 --opt kernel_variant=6 > $O/${T}_bench_streams3_one_per_simd.json 2>> $O/${T}_bench.err
+timeout -k 10 100 python bench.py --no-cpu-baseline --steps 24 --streams 1 --sort-by-cost 0 --opt kernel_variant=2 > $O/${T}_bench_streams1_fp64_blocks.json 2>> $O/${T}_bench.err
+timeout -k 10 300 python tools/variant_agreement.py 8192 > $O/${T}_variant_agreement.txt 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${T}pt -- python3 bench.py --workload pt --chains 512 --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_${T}pt.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${T}pt64 -- python3 bench.py --workload pt --chains 64 --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_${T}pt64.log 2>&1
 cp $O/prof_$T/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_config2.csv
@@ -37,7 +39,7 @@ cp $O/prof_${T}pt/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_pt512.csv
 cp $O/prof_${T}pt64/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_pt64.csv
 timeout -k 10 100 python tools/sched_trace.py 64 > $O/${T}_sched_trace_pt64.txt 2>/dev/null
 timeout -k 10 200 python tools/tail_table.py --json $O/${T}_tail_decades.json --settings shipped > $O/${T}_tail_decades.txt 2>/dev/null
-timeout -k 10 200 python tools/stamps.py --variant 2,4 --batch 1024 > $O/${T}_stamps.txt 2>/dev/null
+timeout -k 10 200 python tools/stamps.py --variant 6,2,4 --batch 1024 > $O/${T}_stamps.txt 2>/dev/null
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -o $O/microbench tools/microbench.hip 2>/dev/null && timeout -k 5 120 $O/microbench 256 > $O/${T}_microbench.txt 2>&1; rm -f $O/microbench
 timeout -k 10 600 python tools/config5_sweep.py $O/${T}_config5_sweep.json > $O/${T}_config5_sweep.txt 2>/dev/null
 timeout -k 10 100 python tools/solve_latency.py > $O/${T}_solve_latency.txt 2>/dev/null

@@ -89,13 +89,13 @@ __device__ inline void body(BK &bk, double *out, long long *cyc, int iters)
     if (threadIdx.x == 0) { out[blockIdx.x] = s + sink[0]; cyc[blockIdx.x] = t1 - t0; }
 }
 
-template <int WHAT>
+template <int WHAT, bool F32BLK>
 __global__ __launch_bounds__(64, 1) void bench_wave(const double *par, double *out, long long *cyc, int iters)
 {
     __shared__ double2 fac_lds[kFactorLdsBytes / 16];
-    WaveBackend bk(threadIdx.x, fac_lds);
+    WaveBackendT<F32BLK> bk(threadIdx.x, fac_lds);
     bk.set_problem(make_par<double>(par, 2000.0 / 128), 128);
-    body<WaveBackend, WHAT>(bk, out, cyc, iters);
+    body<WaveBackendT<F32BLK>, WHAT>(bk, out, cyc, iters);
 }
 template <int WHAT, int NREG>
 __global__ __launch_bounds__(128, 1) void bench_pair(const double *par, double *out, long long *cyc, int iters)
@@ -118,7 +118,7 @@ int main(int argc, char **argv)
     hipMemcpy(d_par, par, sizeof(par), hipMemcpyHostToDevice);
     const int iters = 2000;
     std::vector<long long> c(4096);
-    double res[2][NWHAT];
+    double res[3][NWHAT];
 #define RUN(K, W, KERN, T)                                                                            \
     {                                                                                                 \
         for (int rep = 0; rep < 2; ++rep) {                                                           \
@@ -130,9 +130,9 @@ int main(int argc, char **argv)
         for (int i = 0; i < nblk; ++i) m += c[i];                                                     \
         res[K][W] = m / nblk / iters;                                                                 \
     }
-#define BOTH(W) RUN(0, W, (bench_wave<W>), 64) RUN(1, W, (bench_pair<W, 3>), 128)
+#define BOTH(W) RUN(0, W, (bench_wave<W, true>), 64) RUN(1, W, (bench_wave<W, false>), 64) RUN(2, W, (bench_pair<W, 3>), 128)
     BOTH(RHS) BOTH(APPLY) BOTH(BUILD) BOTH(REDUCE2) BOTH(REDUCE4) BOTH(PUBLISH) BOTH(PREDICT) BOTH(CORRECT) BOTH(DENSE) BOTH(STEP)
-    printf("%-12s %12s %12s   (cycles per call, %d workgroups)\n", "block", "wave", "pair<2,3>", nblk);
-    for (int w = 0; w < NWHAT; ++w) printf("%-12s %12.0f %12.0f\n", kNames[w], res[0][w], res[1][w]);
+    printf("%-12s %12s %12s %12s   (cycles per call, %d workgroups)\n", "block", "wave fp32blk", "wave fp64blk", "pair<2,3>", nblk);
+    for (int w = 0; w < NWHAT; ++w) printf("%-12s %12.0f %12.0f %12.0f\n", kNames[w], res[0][w], res[1][w], res[2][w]);
     return 0;
 }
