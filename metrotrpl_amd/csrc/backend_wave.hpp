@@ -2,15 +2,20 @@
 // grid nodes 2l, 2l+1 (N_i, P_i and the edge field E_i on the LEFT face of each), so nx <= 128.  The
 // whole solver state lives on the CU (Nordsieck history and Newton vectors in this wave's VGPRs/AGPRs,
 // Newton matrix factors in its LDS slab); HBM is touched for the per-solve descriptor, the output
-// sample times and the nt output samples only.  The throughput kernel of a full batch: one wave per
-// SIMD, 1024 resident solves.
+// sample times and the nt output samples only.
 //
 // Linear algebra of I - c*J (block tridiagonal, 2x2 blocks in (dN_i, dP_i) after the per-edge
 // elimination of the field, model_physics.hpp): one in-lane cyclic-reduction level followed by 6
 // parallel-cyclic-reduction levels over the 64 lanes (nearest-neighbour exchange by DPP wave shifts,
-// longer strides by ds_bpermute; one wave per workgroup, so no barriers); all 17 elimination blocks per
-// lane are kept in this wave's 34 KB LDS slab as 16-byte rows, so each further Newton iteration is a
-// cheap re-solve.
+// stride 32 by v_permlane32_swap, the strides between by ds_bpermute; one wave per workgroup, so no
+// barriers); all 17 elimination blocks per lane are kept in this wave's LDS slab as 16-byte rows, so each
+// further Newton iteration is a cheap re-solve.
+//
+// Kernels (bottom of the file): solve_kernel_wave1 / solve_kernel_wave2 -- the default: fp64 factorisation,
+// blocks stored as fp32 (17 KB of LDS per wave), re-solve in packed fp32 on an fp64 right-hand side; built
+// with the whole register file (one solve per SIMD: the shortest solve) and on a 256-register budget (two
+// solves per SIMD: the second wave fills the issue slots the first leaves waiting), same arithmetic, same
+// results.  solve_kernel_wave -- fp64 blocks (34 KB) and an fp64 re-solve: the exact linear algebra.
 #pragma once
 #include "solve_core.hpp"
 
@@ -19,11 +24,11 @@ namespace mtrpl {
 constexpr int kFactorLdsBytes = 17 * 2 * 64 * 16;  // 34816 B per wave
 constexpr int kFactorLdsBytesF32 = 17 * 64 * 16;     // 17408 B per wave with blocks stored as 4 floats
 
-// F32BLK: the elimination blocks are STORED rounded to fp32 (one 16-byte row per block and lane), all
-// arithmetic stays fp64.  The blocks only define the approximate inverse the simplified Newton iteration
-// uses, the residual is fp64: the iteration converges to the same corrector solution (measured: same step
-// counts, +0.7 % Newton iterations, per-decade accuracy table unchanged).  Halves the LDS slab, which is
-// what lets two solves share a SIMD (solve_kernel_wave2).
+// F32BLK: the elimination blocks are STORED rounded to fp32 (one 16-byte row per block and lane) and the
+// re-solve exchanges and multiplies in packed fp32 (apply_f32); factorisation, residual, state and the running
+// right-hand side of the re-solve stay fp64.  The blocks only define the approximate inverse the simplified
+// Newton iteration applies to an fp64 residual: the iteration converges to the same corrector solution
+// (measured: same step counts, +0.7 % Newton iterations, per-decade accuracy table unchanged).
 template <bool F32BLK>
 struct WaveBackendT {
     using real = double;
