@@ -1,6 +1,6 @@
 """Phase breakdown of a solve from the -DMTRPL_STAMPS diagnostic build (dev tool; the product library has
 no stamps).  Builds metrotrpl_amd/lib/libmetrotrpl_amd_stamps.so if needed.
-usage: python tools/stamps.py [--variant 2] [--batch 1024]"""
+usage: python tools/stamps.py [--variant 6,2] [--batch 1024]   (6: the default wave kernel, 2: its fp64-block form)"""
 import argparse
 import os
 import subprocess
@@ -19,7 +19,7 @@ sys.path.insert(0, REPO)
 from metrotrpl_amd import _lib as L, batch, workloads as W  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--variant", default="2")
+ap.add_argument("--variant", default="6,2")
 ap.add_argument("--batch", type=int, default=1024)
 a = ap.parse_args()
 c = W.config2(a.batch)
