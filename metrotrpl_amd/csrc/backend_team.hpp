@@ -14,7 +14,10 @@
 
 namespace mtrpl {
 
-template <class T_, int W, bool TRAPS_, bool GBLK>
+// BF32 (fp64 solves only): the elimination blocks are stored rounded to fp32, one 16-byte row per block and
+// thread -- half the bytes of the slab the W = 4 kernel streams on every re-solve.  As in the wave kernels they
+// only define the approximate inverse the simplified Newton iteration applies to an fp64 residual.
+template <class T_, int W, bool TRAPS_, bool GBLK, bool BF32 = false>
 struct TeamBackend {
     using real = T_;
     using row_t = vec2_t<real>;  // one 2-value row (16 B in fp64)
@@ -26,7 +29,7 @@ struct TeamBackend {
     static constexpr int NBLK = 5 + 2 * LEVELS;                              // elimination blocks per thread
     static constexpr int KMAX = 6;                                           // rows per exchange
     static constexpr int kXbufRows = 2 * KMAX * T;
-    static constexpr int kBlkRows = NBLK * 2 * T;
+    static constexpr int kBlkRows = (BF32 ? NBLK : NBLK * 2) * T;  // in units of 16 bytes (fp64 solves)
     static constexpr int kRbufVals = 2 * 4 * W + W + 4;
     enum { BINV_E = 0, BIA_E, BIC_E, CR_AL, CR_GA, PAL0 = 5 };
 
@@ -42,7 +45,7 @@ struct TeamBackend {
     real tq[2], tca[2];  // traps: 1/(1+c b_i), c a_i   (dNt_i = tq*(bNt + tca*dN_i))
     real tcb[2];         // traps: c b_i * tq          (rN_i += tcb * bNt_i)
     M2r Bfin;
-    row_t *blk;  // [NBLK][2][T] rows: elimination blocks of this thread at [.][.][tid]
+    row_t *blk;  // [NBLK][2][T] rows (BF32: [NBLK][T] float4): elimination blocks of this thread at [.][.][tid]
 
     __device__ inline TeamBackend(int tid_, row_t *xbuf_, real *rbuf_, row_t *blk_) : xbuf(xbuf_), rbuf(rbuf_), blk(blk_)
     {
@@ -163,13 +166,22 @@ struct TeamBackend {
 
     __device__ inline void put(int b, const M2r &m) const
     {
-        blk[(b * 2 + 0) * T + tid] = row_t{m.a, m.b};
-        blk[(b * 2 + 1) * T + tid] = row_t{m.c, m.d};
+        if constexpr (BF32) {
+            reinterpret_cast<float4 *>(blk)[b * T + tid] = float4{(float)m.a, (float)m.b, (float)m.c, (float)m.d};
+        } else {
+            blk[(b * 2 + 0) * T + tid] = row_t{m.a, m.b};
+            blk[(b * 2 + 1) * T + tid] = row_t{m.c, m.d};
+        }
     }
     __device__ inline M2r get(int b) const
     {
-        const row_t u = blk[(b * 2 + 0) * T + tid], v = blk[(b * 2 + 1) * T + tid];
-        return M2r{u.x, u.y, v.x, v.y};
+        if constexpr (BF32) {
+            const float4 q = reinterpret_cast<const float4 *>(blk)[b * T + tid];
+            return M2r{(real)q.x, (real)q.y, (real)q.z, (real)q.w};
+        } else {
+            const row_t u = blk[(b * 2 + 0) * T + tid], v = blk[(b * 2 + 1) * T + tid];
+            return M2r{u.x, u.y, v.x, v.y};
+        }
     }
 
     // ---- RHS ----
@@ -385,7 +397,7 @@ struct TeamBackend {
 // GBLK: the elimination blocks live in a per-solve slab in HBM (W = 4: 172 KB per solve do not fit LDS
 // next to the exchange buffers; the slab is L2/MALL-resident and read as coalesced 16-byte rows).
 // `gblk` is private to this launch (mtrpl_capi.hip takes it from a per-launch pool).
-template <class T_, int W, bool TRAPS, bool GBLK>
+template <class T_, int W, bool TRAPS, bool GBLK, bool BF32 = false>
 __global__ __launch_bounds__(64 * W) void solve_kernel_team(const mtrpl_solve_desc *__restrict__ descs,
                                                              const double *__restrict__ ini,
                                                              const double *__restrict__ tsteps,
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_team(const mtrpl_solve_de
                                                              int32_t *__restrict__ stats, int64_t B, SolveTuning tune,
                                                              void *__restrict__ gblk)
 {
-    using BK = TeamBackend<T_, W, TRAPS, GBLK>;
+    using BK = TeamBackend<T_, W, TRAPS, GBLK, BF32>;
     using row_t = typename BK::row_t;
     const int64_t sidx = blockIdx.x;
     const unsigned long long clk0_ = __builtin_amdgcn_s_memtime();

@@ -317,12 +317,12 @@ int take_slab(mtrpl_ctx *ctx, size_t need, hipStream_t s, Slab **out)
     return MTRPL_OK;
 }
 
-template <class T, int W, bool TRAPS, bool GBLK>
+template <class T, int W, bool TRAPS, bool GBLK, bool BF32 = false>
 void launch_team(hipStream_t s, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
                  const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats,
                  const SolveTuning &tune, void *gblk)
 {
-    hipLaunchKernelGGL((solve_kernel_team<T, W, TRAPS, GBLK>), dim3((unsigned)B), dim3(64 * W), 0, s, d_descs, d_ini,
+    hipLaunchKernelGGL((solve_kernel_team<T, W, TRAPS, GBLK, BF32>), dim3((unsigned)B), dim3(64 * W), 0, s, d_descs, d_ini,
                        d_tsteps, d_out, d_status, d_stats, B, tune, gblk);
 }
 template <class T>
@@ -330,22 +330,31 @@ int launch_team_any(mtrpl_ctx *ctx, hipStream_t s, int64_t B, const mtrpl_solve_
                     const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats, int32_t max_nx,
                     bool traps)
 {
+    // fp64 solves store their elimination blocks as fp32 (half the LDS: twice the workgroups per CU at W = 2)
+    constexpr bool kF32 = sizeof(T) == 8;
 #define MTRPL_TEAM(W_, G_, P_)                                                                                       \
     do {                                                                                                             \
-        if (traps) launch_team<T, W_, true, G_>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, P_); \
-        else launch_team<T, W_, false, G_>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, P_);      \
+        if (traps) launch_team<T, W_, true, G_, kF32>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, P_); \
+        else launch_team<T, W_, false, G_, kF32>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, P_);      \
     } while (0)
     if (max_nx <= 128) MTRPL_TEAM(1, false, nullptr);
     else if (max_nx <= 256) MTRPL_TEAM(2, false, nullptr);
     else {
-        // 4 waves per solve: the 21 elimination blocks per thread (172 KB per solve in fp64) do not fit in
-        // LDS next to the exchange buffers -> per-solve slab in HBM (L2/MALL-resident), private to this launch
-        const size_t need = (size_t)B * TeamBackend<T, 4, false, true>::kBlkRows * sizeof(typename TeamBackend<T, 4, false, true>::row_t);
-        Slab *sl = nullptr;
-        const int rc = take_slab(ctx, need, s, &sl);
-        if (rc != MTRPL_OK) return rc;
-        MTRPL_TEAM(4, true, sl->p);
-        HIP_TRY(ctx, hipEventRecord(sl->done, s));
+        // 4 waves per solve, 21 elimination blocks per thread.  fp64 solves store them as fp32 (86 KB per solve):
+        // that fits in LDS next to the exchange buffers (135 KB of the CU's 160; the register file allows one
+        // such workgroup per CU anyway).  The fp32 instantiation (precision sweeps) keeps its blocks in a
+        // per-solve slab in HBM, private to this launch.
+        if constexpr (kF32) {
+            MTRPL_TEAM(4, false, nullptr);
+        } else {
+            using BK4 = TeamBackend<T, 4, false, true>;
+            const size_t need = (size_t)B * BK4::kBlkRows * sizeof(typename BK4::row_t);
+            Slab *sl = nullptr;
+            const int rc = take_slab(ctx, need, s, &sl);
+            if (rc != MTRPL_OK) return rc;
+            MTRPL_TEAM(4, true, sl->p);
+            HIP_TRY(ctx, hipEventRecord(sl->done, s));
+        }
     }
 #undef MTRPL_TEAM
     return MTRPL_OK;
