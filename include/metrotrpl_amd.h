@@ -27,7 +27,12 @@
  *    per-context pool and only re-used once the launch has completed or by a
  *    later launch on the same stream.  The context itself is not thread-safe:
  *    one host thread issues the calls;
- *  - all arithmetic is IEEE fp64.
+ *  - state, residual, right-hand side, Jacobian, output samples and every helper function are IEEE fp64.
+ *    Two things inside the solve kernels are not: the LINEAR ALGEBRA of the simplified
+ *    Newton iteration is factorised in fp64 but its elimination blocks are stored rounded to fp32 and re-applied in
+ *    fp32 -- an approximate inverse on an fp64 residual, so the corrector converges to the same fp64 solution
+ *    (kernel_variant 2 keeps fp64 blocks and an fp64 re-solve) -- and the error norms / step-size controller, which
+ *    only steer the integration, are evaluated in fp32.
  */
 #ifndef METROTRPL_AMD_H
 #define METROTRPL_AMD_H
@@ -122,7 +127,13 @@ const char *mtrpl_version(void);
  *                                     after a rejected one; nq_bias_same/_down/_up: multipliers of the step factors
  *   early_factor, early_frac          local tolerance x early_factor for steps that end before
  *                                     early_frac * (first requested sample time)
- *   honor_hmax                        1: desc.hmax is the maximum step (the reference's max_step)
+ *   honor_hmax                        1: desc.hmax is the maximum step (the reference's max_step) ...
+ *   hmax_deep                         ... while there is a signal: once an emitted sample has fallen below hmax_deep x
+ *                                     the first sample (default 1e-11: the state sits at equilibrium to rounding) the
+ *                                     error test alone sets the step for the rest of the solve (the flag latches and is
+ *                                     evaluated at output samples); 0: desc.hmax always holds
+ *   fresh_jac                         accepted and ignored (removed in round 2: the Jacobian is always refreshed at a
+ *                                     refactorisation)
  *   max_steps                         a solve that needs more stops early (status 1, tail zero-filled)
  *   kernel_variant                    std model, nx <= 128: 0 automatic -- the wave kernel (one wavefront per solve)
  *                                     with the elimination blocks stored as fp32 and the re-solve in packed fp32 on

@@ -43,12 +43,13 @@ __device__ inline double simpson_uniform(F val, int NU, double du)
 
 // laplace.py:129-167 (I_moment): dt * simpson((u - 1/2)^n * linspace(y[m+1-u_lower], y[m+1-u_upper], NU), dx = du),
 // u = linspace(u_lower, u_upper, NU).
-__device__ inline double irf_moment(const double *__restrict__ t, const double *__restrict__ y, int m, int n,
+// ia, ib: the (already wrapped, numpy-style) indices m+1-u_lower, m+1-u_upper
+__device__ inline double irf_moment(const double *__restrict__ t, const double *__restrict__ y, int ia, int ib, int n,
                                     int u_lower, int u_upper, int NU)
 {
     const double dt = t[1] - t[0];
     const double du = linspace_at((double)u_lower, (double)u_upper, NU, 1) - linspace_at((double)u_lower, (double)u_upper, NU, 0);
-    const double ya = y[m + 1 - u_lower], yb = y[m + 1 - u_upper];
+    const double ya = y[ia], yb = y[ib];
     auto val = [&](int i) {
         const double u = linspace_at((double)u_lower, (double)u_upper, NU, i);
         const double yi = linspace_at(ya, yb, NU, i);
@@ -67,13 +68,13 @@ __global__ void make_I_table_kernel(const double *__restrict__ t, const double *
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 3 * nk) return;
     const int m = idx / 3, n = idx % 3;
-    table[idx] = (m >= nk - 1) ? 0.0 : irf_moment(t, y, m, n, 0, 1, 1000);
+    table[idx] = (m >= nk - 1) ? 0.0 : irf_moment(t, y, m + 1, m, n, 0, 1, 1000);
 }
 // one moment with the caller's settings (laplace.I_moment)
-__global__ void I_moment_kernel(const double *__restrict__ t, const double *__restrict__ y, int m, int n, int u_lower,
-                                int u_upper, int NU, double *__restrict__ out)
+__global__ void I_moment_kernel(const double *__restrict__ t, const double *__restrict__ y, int ia, int ib, int n,
+                                int u_lower, int u_upper, int NU, double *__restrict__ out)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = irf_moment(t, y, m, n, u_lower, u_upper, NU);
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = irf_moment(t, y, ia, ib, n, u_lower, u_upper, NU);
 }
 // forward_solver.py:267-274: calculate_RR / calculate_photoc, element-wise
 __global__ void density_kernel(const double *__restrict__ N, const double *__restrict__ P, int64_t n, int meas, double ks,

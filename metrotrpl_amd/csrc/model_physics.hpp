@@ -1,6 +1,6 @@
 // model_physics.hpp -- the drift-diffusion / recombination model of forward_solver.py:332-418 as
 // per-edge and per-node formulas: right-hand side terms and their analytic derivatives.  Every solver
-// backend (one wave, a wave pair, a team of waves) evaluates exactly these expressions; what differs
+// backend (one wave, a team of waves) evaluates exactly these expressions; what differs
 // between backends is only where the neighbouring node's values come from.
 //
 // Discretisation (forward_solver.py:332-372): nodes i = 0..L-1 carry N_i, P_i; edge i is the LEFT face

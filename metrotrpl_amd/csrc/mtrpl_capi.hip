@@ -13,7 +13,6 @@
 #include "../../include/metrotrpl_amd.h"
 #include "irf_kernels.hpp"
 #include "backend_wave.hpp"
-#include "backend_pair.hpp"
 #include "backend_team.hpp"
 
 using namespace mtrpl;
@@ -51,8 +50,6 @@ struct mtrpl_ctx {
     int two_per_simd_min_batch = 1025;  // kernel_variant 0: launches of at least this many std / nx <= 128 solves use
                                         // the two-solves-per-SIMD build of the wave kernel (more than one solve per
                                         // SIMD anyway), smaller ones the one-per-SIMD build: same results
-    int pair_max_batch = 0;  // kernel_variant 0: launches up to this many solves use the wave-pair kernel (0: never --
-                             // measured: its exchanges cost what the halved per-lane work saves)
 };
 
 #define HIP_TRY(ctx, expr)                                                                   \
@@ -150,17 +147,6 @@ __global__ __launch_bounds__(64) void rhs_batch_kernel_wave(const double *par, c
     WaveBackend bk(threadIdx.x, nullptr);
     rhs_probe(bk, par, dxs, y, dy, nx, s);
 }
-template <int W>
-__global__ __launch_bounds__(64 * W) void rhs_batch_kernel_pair(const double *par, const double *dxs, const double *y,
-                                                                double *dy, int nx, int64_t B)
-{
-    using BK = PairBackend<W, 6>;
-    const int64_t s = blockIdx.x;
-    if (s >= B) return;
-    __shared__ double2 xs_lds[BK::kXchBytes / 16];
-    BK bk(threadIdx.x, nullptr, reinterpret_cast<double *>(xs_lds));
-    rhs_probe(bk, par, dxs, y, dy, nx, s);
-}
 template <int W, bool TRAPS>
 __global__ __launch_bounds__(64 * W) void rhs_batch_kernel_team(const double *par, const double *dxs, const double *y,
                                                                 double *dy, int nx, int64_t B)
@@ -215,20 +201,6 @@ __global__ __launch_bounds__(64) void newton_probe_kernel_wave(const double *par
     WaveBackendT<F32BLK> bk(threadIdx.x, fac_lds);
     newton_probe(bk, par, dxs, cs, y, b, x, nx, s);
 }
-template <int W, int NREG>
-__global__ __launch_bounds__(64 * W) void newton_probe_kernel_pair(const double *par, const double *dxs,
-                                                                   const double *cs, const double *y, const double *b,
-                                                                   double *x, int nx, int64_t B)
-{
-    using BK = PairBackend<W, NREG>;
-    const int64_t s = blockIdx.x;
-    if (s >= B) return;
-    __shared__ double2 blk_lds[BK::kBlkBytes > 0 ? BK::kBlkBytes / 16 : 1];
-    __shared__ double2 xs_lds[BK::kXchBytes / 16];
-    BK bk(threadIdx.x, blk_lds, reinterpret_cast<double *>(xs_lds));
-    newton_probe(bk, par, dxs, cs, y, b, x, nx, s);
-}
-
 // forward_solver.py:26-38: one wave per row, any nx (chunked inclusive scan)
 __global__ __launch_bounds__(64) void e_field_kernel(const double *N, const double *P, double *E, int nx, int64_t rows,
                                                      double n0, double p0, double pref, double corner_E)
@@ -293,27 +265,60 @@ int check_descs(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d, int64_t n_
     return MTRPL_OK;
 }
 
-// a slab of at least `need` bytes that no in-flight launch on another stream is using
+// a slab of at least `need` bytes that no in-flight launch on another stream is using.  The pool holds at most
+// one idle slab that is too small: growing replaces the smallest idle one instead of adding to it, so that a
+// sequence of launches of varying size does not accumulate stale slabs.
 int take_slab(mtrpl_ctx *ctx, size_t need, hipStream_t s, Slab **out)
 {
-    Slab *pick = nullptr;
+    Slab *pick = nullptr, *small = nullptr;
     for (Slab &sl : ctx->slabs) {
-        const bool free_ = (sl.stream == s) || (hipEventQuery(sl.done) == hipSuccess);
-        if (free_ && sl.bytes >= need && (!pick || sl.bytes < pick->bytes)) pick = &sl;
+        bool free_ = sl.stream == s;
+        if (!free_) {
+            const hipError_t q = hipEventQuery(sl.done);
+            if (q == hipSuccess) free_ = true;
+            else if (q != hipErrorNotReady) {
+                ctx->err = std::string("hipEventQuery(slab): ") + hipGetErrorString(q);
+                return MTRPL_ERR_DEVICE;
+            }
+        }
+        if (!free_) continue;
+        if (sl.bytes >= need) { if (!pick || sl.bytes < pick->bytes) pick = &sl; }
+        else if (!small || sl.bytes < small->bytes) small = &sl;
     }
     if (!pick) {
-        Slab sl;
-        HIP_TRY(ctx, hipMalloc(&sl.p, need));
-        sl.bytes = need;
-        if (hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
-            (void)hipFree(sl.p);
-            return bad(ctx, MTRPL_ERR_DEVICE, "hipEventCreate failed");
+        void *p = nullptr;
+        if (small) {  // idle (or ordered before us on this stream) and too small: hipFree waits for the device
+            (void)hipFree(small->p);
+            small->p = nullptr;
+            small->bytes = 0;
         }
-        ctx->slabs.push_back(sl);
-        pick = &ctx->slabs.back();
+        HIP_TRY(ctx, hipMalloc(&p, need));
+        if (small) {
+            small->p = p;
+            small->bytes = need;
+            pick = small;
+        } else {
+            Slab sl;
+            sl.p = p;
+            sl.bytes = need;
+            if (hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
+                (void)hipFree(sl.p);
+                return bad(ctx, MTRPL_ERR_DEVICE, "hipEventCreate failed");
+            }
+            ctx->slabs.push_back(sl);
+            pick = &ctx->slabs.back();
+        }
     }
     pick->stream = s;
     *out = pick;
+    return MTRPL_OK;
+}
+// behind the launch that uses the slab: the event its next user on another stream waits for.  If the launch itself
+// failed the slab is handed back at once (stream = nullptr marks "no launch pending": the stale event is complete).
+int seal_slab(mtrpl_ctx *ctx, Slab *sl, hipStream_t s, bool launched)
+{
+    if (!launched) { sl->stream = nullptr; return MTRPL_OK; }
+    HIP_TRY(ctx, hipEventRecord(sl->done, s));
     return MTRPL_OK;
 }
 
@@ -353,7 +358,10 @@ int launch_team_any(mtrpl_ctx *ctx, hipStream_t s, int64_t B, const mtrpl_solve_
             const int rc = take_slab(ctx, need, s, &sl);
             if (rc != MTRPL_OK) return rc;
             MTRPL_TEAM(4, true, sl->p);
-            HIP_TRY(ctx, hipEventRecord(sl->done, s));
+            const bool launched = hipGetLastError() == hipSuccess;
+            const int rs = seal_slab(ctx, sl, s, launched);
+            if (!launched) return bad(ctx, MTRPL_ERR_DEVICE, "team kernel launch failed");
+            if (rs != MTRPL_OK) return rs;
         }
     }
 #undef MTRPL_TEAM
@@ -446,11 +454,11 @@ int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value)
         if (k == o.key) { ctx->tune.*(o.m) = (int)value; return MTRPL_OK; }
     if (k == "kernel_variant") {
         const int v = (int)value;
-        if (v != 0 && v != 1 && v != 2 && v != 3 && v != 4 && v != 5 && v != 6)
-            return bad(ctx, MTRPL_ERR_BAD_ARG, "kernel_variant must be 0 (auto), 1 (team), 2 (wave, fp64 blocks), 3 / 6 (wave, fp32 blocks, two / one per SIMD), 4 or 5 (wave pair)");
+        if (v != 0 && v != 1 && v != 2 && v != 3 && v != 6)
+            return bad(ctx, MTRPL_ERR_BAD_ARG, "kernel_variant must be 0 (auto), 1 (team), 2 (wave, fp64 blocks), 3 / 6 (wave, fp32 blocks, two / one per SIMD)");
         ctx->kernel_variant = v;
-    } else if (k == "pair_max_batch") {
-        ctx->pair_max_batch = (int)value;
+    } else if (k == "fresh_jac") {
+        // removed in round 2 (the Jacobian is always refreshed at a refactorisation): accepted and ignored
     } else if (k == "two_per_simd_min_batch") {
         ctx->two_per_simd_min_batch = (int)value;
     } else if (k == "precision") {
@@ -471,7 +479,6 @@ int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value)
     for (const OptI &o : kOptI)
         if (k == o.key) { *value = ctx->tune.*(o.m); return MTRPL_OK; }
     if (k == "kernel_variant") *value = ctx->kernel_variant;
-    else if (k == "pair_max_batch") *value = ctx->pair_max_batch;
     else if (k == "two_per_simd_min_batch") *value = ctx->two_per_simd_min_batch;
     else if (k == "precision") *value = ctx->precision;
     else return MTRPL_ERR_BAD_ARG;
@@ -504,11 +511,9 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
     //              second once the SIMDs are over-subscribed (the second wave fills the issue slots the first
     //              leaves waiting)
     //   wave  (2): fp64 blocks and an fp64 re-solve: the exact linear algebra, one solve per SIMD
-    //   pair  (4): two waves per solve, one node per lane, blocks in registers (opt-in: pair_max_batch)
-    //   pair  (5): the same with every block in LDS and a register budget for two waves per SIMD
     int variant = ctx->kernel_variant;
     if (variant == 0)
-        variant = (!traps && max_nx <= 128 && B <= ctx->pair_max_batch) ? 4 : ((B >= ctx->two_per_simd_min_batch) ? 3 : 6);
+        variant = (B >= ctx->two_per_simd_min_batch) ? 3 : 6;
     const bool ct = default_tune(ctx->tune);
 #define MTRPL_WAVE(KERNEL)                                                                                            \
     do {                                                                                                              \
@@ -520,13 +525,6 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
     if (traps || max_nx > 128 || variant == 1) {
         const int rc = launch_team_any<double>(ctx, s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, max_nx, traps);
         if (rc != MTRPL_OK) return rc;
-    } else if (variant == 4 || variant == 5) {
-#define MTRPL_PAIR(W_, NREG_, MINW_)                                                                                  \
-    hipLaunchKernelGGL((solve_kernel_pair<W_, NREG_, MINW_>), dim3((unsigned)B), dim3(64 * W_), 0, s, d_descs, d_ini, \
-                       d_tsteps, d_out, d_status, d_stats, B, ctx->tune)
-        if (max_nx <= 64) { if (variant == 4) MTRPL_PAIR(1, 6, 1); else MTRPL_PAIR(1, 0, 2); }
-        else { if (variant == 4) MTRPL_PAIR(2, 3, 1); else MTRPL_PAIR(2, 0, 2); }
-#undef MTRPL_PAIR
     } else if (variant == 3) {
         MTRPL_WAVE(solve_kernel_wave2);
     } else if (variant == 6) {
@@ -595,10 +593,7 @@ int mtrpl_rhs_batch(mtrpl_ctx *ctx, int64_t B, int32_t nx, int32_t model, const 
 #define MTRPL_RHS_ARGS dim3((unsigned)B), dim3(64 * W_), 0, s, dp.as<double>(), ddx.as<double>(), dy_in.as<double>(), dy_out.as<double>(), nx, B
 #define MTRPL_RHS_TEAM(W__, T_) do { constexpr int W_ = W__; hipLaunchKernelGGL((rhs_batch_kernel_team<W__, T_>), MTRPL_RHS_ARGS); } while (0)
     const int variant = ctx->kernel_variant;
-    if (nx <= 128 && !traps && (variant == 4 || variant == 5)) {
-        if (nx <= 64) { constexpr int W_ = 1; hipLaunchKernelGGL((rhs_batch_kernel_pair<1>), MTRPL_RHS_ARGS); }
-        else { constexpr int W_ = 2; hipLaunchKernelGGL((rhs_batch_kernel_pair<2>), MTRPL_RHS_ARGS); }
-    } else if (nx <= 128 && !traps && variant != 1) {
+    if (nx <= 128 && !traps && variant != 1) {
         constexpr int W_ = 1;
         hipLaunchKernelGGL(rhs_batch_kernel_wave, MTRPL_RHS_ARGS);
     }
@@ -637,12 +632,7 @@ int mtrpl_newton_probe(mtrpl_ctx *ctx, int64_t B, int32_t nx, const double *par,
     HIP_TRY(ctx, hipMemcpyAsync(db.p, b, sizeof(double) * S * B, hipMemcpyHostToDevice, s));
 #define MTRPL_NP_ARGS 0, s, dp.as<double>(), ddx.as<double>(), dc.as<double>(), dyy.as<double>(), db.as<double>(), dxo.as<double>(), nx, B
     const int variant = ctx->kernel_variant;
-    if (variant == 4 || variant == 5) {
-        if (nx <= 64 && variant == 4) hipLaunchKernelGGL((newton_probe_kernel_pair<1, 6>), dim3((unsigned)B), dim3(64), MTRPL_NP_ARGS);
-        else if (nx <= 64) hipLaunchKernelGGL((newton_probe_kernel_pair<1, 0>), dim3((unsigned)B), dim3(64), MTRPL_NP_ARGS);
-        else if (variant == 4) hipLaunchKernelGGL((newton_probe_kernel_pair<2, 3>), dim3((unsigned)B), dim3(128), MTRPL_NP_ARGS);
-        else hipLaunchKernelGGL((newton_probe_kernel_pair<2, 0>), dim3((unsigned)B), dim3(128), MTRPL_NP_ARGS);
-    } else if (variant == 3 || variant == 6 || variant == 0) {
+    if (variant == 3 || variant == 6 || variant == 0) {
         hipLaunchKernelGGL(newton_probe_kernel_wave<true>, dim3((unsigned)B), dim3(64), MTRPL_NP_ARGS);
     } else {
         hipLaunchKernelGGL(newton_probe_kernel_wave<false>, dim3((unsigned)B), dim3(64), MTRPL_NP_ARGS);

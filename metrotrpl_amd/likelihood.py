@@ -137,12 +137,24 @@ class LikelihoodEngine:
         d, ld, ini_arr, fit = tm["d"].copy(), tm["ld"], tm["ini_arr"], tm["fit"]
         d["par"] = np.repeat(batch.pack_params(states * self.units, self.indexes), self.M, axis=0)
         if fit["fluences"] is not None or fit["absps"] is not None:
-            ini3 = tm["ini3"].copy()  # a COPY of the init row is scaled (the reference compounds in place, :44/:51)
-            for key, col in (("fluences", 0), ("absps", 1)):
-                if fit[key] is not None:
-                    use, r, i = fit[key]
-                    ini3[use, col] *= states[r, i]
-            d["ini"] = ini3
+            # a COPY of the init row is scaled (the reference compounds in place, :44/:51).  The factors act on
+            # elements 0 and 1 of the measurement's init-params row whatever the row means: [fluence, alpha, ..]
+            # in fluence mode, the densities of nodes 0 and 1 in density mode (trial_move_evaluation.py:44,:51
+            # index iniPar[0] / iniPar[1] without looking at ini_mode).
+            if self.ini_mode == "density":
+                ini_arr = ini_arr.reshape(d.shape[0], -1).copy()  # per launch: bypasses the _const cache
+                for key, col in (("fluences", 0), ("absps", 1)):
+                    if fit[key] is not None:
+                        use, r, i = fit[key]
+                        ini_arr[use, col] *= states[r, i]
+                ini_arr = ini_arr.reshape(-1)
+            else:
+                ini3 = tm["ini3"].copy()
+                for key, col in (("fluences", 0), ("absps", 1)):
+                    if fit[key] is not None:
+                        use, r, i = fit[key]
+                        ini3[use, col] *= states[r, i]
+                d["ini"] = ini3
         if fit["scale"] is not None:
             use, r, i = fit["scale"]
             ld = ld.copy()

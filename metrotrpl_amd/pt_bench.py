@@ -204,3 +204,25 @@ def pmc_fields(solves_per_launch=1024, kernel="solve_kernel_wave1"):
     except Exception:
         pass
     return out
+
+
+N_SIMD, CLOCK_HZ = 1024, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz max clock
+
+
+def valu_issue_fields(kernel, solves_per_sec_per_gpu):
+    """The binding roofline of the solve kernel: vector-ALU issue.  Instructions and VALU-busy cycles per solve
+    come from the committed rocprofv3 --pmc SQ_* pass of the named kernel (not measured in this run); frac = the
+    share of the device's SIMD-cycles (1024 SIMDs x 2.4 GHz nominal) the measured solve rate keeps the vector
+    ALUs busy."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name = "hbm_traffic_wave2.json" if kernel.endswith("wave2") else "hbm_traffic.json"
+    try:
+        z = json.load(open(os.path.join(repo, "profiles", name)))
+        sq, d = z["sq_counters_per_launch"], z["derived"]
+        busy = 4.0 * sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVES"]  # SQ_ACTIVE_* count quad-cycles
+        return {"insts_per_solve": d["valu_insts_per_solve"], "busy_cycles_per_solve": busy,
+                "frac": solves_per_sec_per_gpu * busy / (N_SIMD * CLOCK_HZ), "peak": "1024 SIMDs x 2.4 GHz",
+                "source": f"profiles/{name} (rocprofv3 --pmc SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_WAVES of {kernel}); "
+                          "the solve rate is this run's"}
+    except Exception as e:
+        return {"error": repr(e)}

@@ -39,5 +39,12 @@ if __name__ == "__main__":
         vals.append(lp.I_moment(irf[:, 0], irf[:, 1], m, n, u_lower=lo, u_upper=hi, u_spacing=nu))
     out["moment_cases"] = np.array(cases)
     out["moment_vals"] = np.array(vals)
+    # bounds that take y[m+1-u] to a NEGATIVE index: numpy wraps around (laplace.py:164), no IndexError
+    wcases, wvals = [], []
+    for (m, n, lo, hi, nu) in ((0, 1, 0, 3, 100), (1, 0, 5, 1, 50), (2, 2, 0, 150, 33)):
+        wcases.append([m, n, lo, hi, nu])
+        wvals.append(lp.I_moment(irf[:, 0], irf[:, 1], m, n, u_lower=lo, u_upper=hi, u_spacing=nu))
+    out["moment_wrap_cases"] = np.array(wcases)
+    out["moment_wrap_vals"] = np.array(wvals)
     np.savez_compressed(os.path.join(HERE, "helpers.npz"), **out)
     print("wrote helpers.npz:", {k: np.shape(v) for k, v in out.items()})

@@ -245,3 +245,30 @@ def test_loglik_argmax_of_hand_made_traces():
     # the cases really differ in where the maximum sits: early, middle, end
     assert shifts[4] < 0.01 * span and 0.6 * span < shifts[0] < 0.8 * span and 0.2 * span < shifts[1] < 0.3 * span
     assert shifts[3] > 0.7 * span and shifts[5] > 0.9 * span
+
+
+@pytest.mark.parametrize("mode", ["density", "fluence"])
+def test_fittable_fluence_and_absorption_factors(mode):
+    """trial_move_evaluation.py:38-52: the fittable factors multiply elements 0 / 1 of the init-params row in both
+    ini_modes -- in density mode the densities of nodes 0 and 1 (the engine dropped them there).
+    Against the reference's golden log-likelihoods (LSODA at rtol 1e-7: 2e-6) and the tight oracle (1e-6)."""
+    from oracle import oracle as O
+    from tests.test_oracle_solve import _fittable_setup
+    from metrotrpl_amd.likelihood import engine_from_fields
+    ev, state, uniq, shared = _fittable_setup(mode)
+    eng = engine_from_fields(shared, uniq)
+    T = [1.0, 3.0, 7.5]
+    states = np.stack([state, state])
+    pidx = shared["_param_indexes"]
+    states[1, pidx["_f0"]] = 1.0   # second chain: no change of measurement 0's first element
+    states[1, pidx["_a0"]] = 0.8
+    table = eng.eval(states, T)
+    np.testing.assert_allclose(table[0], ev[mode + "__ll_meas"], rtol=3e-6)
+    tight = dict(shared, rtol=1e-10, atol=1e-14)
+    for c in range(2):
+        _, ref = O.eval_trial_move(states[c], uniq, tight, temperatures=T)
+        np.testing.assert_allclose(table[c], ref, rtol=1e-6)
+    assert not np.allclose(table[0], table[1], rtol=1e-3)
+    # the engine scales a copy: the caller's rows are untouched and a second evaluation gives the same table
+    np.testing.assert_array_equal(shared["_init_params"], ev[mode + "__ini"])
+    np.testing.assert_array_equal(eng.eval(states, T), table)

@@ -70,7 +70,7 @@ def test_rhs_matches_reference(rhsg):
         ref = rhsg[f"std{k}_dy"]
         # dN, dP are differences of fluxes ~1e3x larger than the result: scale by the flux magnitude
         scale = np.max(np.abs(ref[:2 * L])) + 1e-300
-        for variant in (2, 4):  # the single-wave layout and the wave-pair layout (boundary node via LDS)
+        for variant in (2, 1):  # the single-wave layout and the team layout (boundary node via LDS)
             ctx.set_option("kernel_variant", variant)
             try:
                 dy = batch.rhs_batch(par, [a[1]], y[None, :], L)[0]
@@ -83,11 +83,11 @@ def test_rhs_matches_reference(rhsg):
 
 
 def test_newton_linear_solver():
-    """E-elimination + cyclic reduction (+ the SPIKE interface of the wave-pair backend) == dense solve of
+    """E-elimination + cyclic reduction == dense solve of
     (I - cJ) x = b."""
     from metrotrpl_amd import _lib as L, batch, workloads as W
     ctx = L.default_context()
-    from tools.proto_ndf import Problem
+    from tests.dense_model import Problem
     ix, un = W.indexes(), W.units()
     c2 = W.config2(6)
     rng = np.random.default_rng(0)
@@ -106,9 +106,8 @@ def test_newton_linear_solver():
                 b[2 * nx] = 0.0
                 b[-1] = 0.0
                 x_ref = np.linalg.solve(M, b)
-                # one wave, fp64 blocks | one wave, fp32-stored blocks + packed fp32 re-solve (the default) | wave pair,
-                # blocks in registers | wave pair, blocks in LDS
-                for variant in (2, 3, 4, 5):
+                # one wave, fp64 blocks | one wave, fp32-stored blocks + fp32 re-solve (the default)
+                for variant in (2, 3):
                     ctx.set_option("kernel_variant", variant)
                     try:
                         x = batch.newton_probe(par, [prob.dx], [c], y[None, :], b[None, :], nx)[0]
@@ -269,15 +268,15 @@ def test_hard_cases_tauP_much_larger_than_tauN():
 
 def test_every_backend_lands_on_the_converged_traces():
     """kernel_variant 6 / 3 (one wave per solve, fp32-stored elimination blocks, one / two solves per SIMD: the
-    default pair), 2 (fp64 blocks), 4 / 5 (wave pair: SPIKE interface between the waves, blocks in registers / in
-    LDS) and 1 (team kernel) are different distributions of the same integrator: all within the gate on the hard
-    cases, and not one kernel behind six switches.  The two builds of the default kernel give the same bits."""
+    default pair), 2 (fp64 blocks) and 1 (team kernel) are different distributions of the same integrator: all within
+    the gate on the hard cases, and not one kernel behind four switches.  The two builds of the default kernel give
+    the same bits."""
     from metrotrpl_amd import _lib as L, batch
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "hard_cases.npz"))
     idx = {n: i for i, n in enumerate(str(z["names"]).split(","))}
     ctx = L.default_context()
     out = {}
-    variants = (6, 3, 2, 4, 5, 1)
+    variants = (6, 3, 2, 1)
     try:
         for variant in variants:
             ctx.set_option("kernel_variant", variant)
@@ -292,7 +291,7 @@ def test_every_backend_lands_on_the_converged_traces():
         m = np.abs(ref) >= 1e-4 * abs(ref[0])
         for variant in variants:
             assert np.max(np.abs(out[variant][k][m] - ref[m]) / np.abs(ref[m])) <= 1e-6, (variant, k)
-    assert not np.array_equal(out[2], out[4]) and not np.array_equal(out[2], out[3])  # (the one-wave team kernel reproduces the wave kernel bit for bit)
+    assert not np.array_equal(out[2], out[3])
     np.testing.assert_array_equal(out[6], out[3])  # one or two solves per SIMD: the same arithmetic
 
 

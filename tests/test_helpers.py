@@ -33,8 +33,14 @@ def test_I_moment_any_spacing(h):
         got = laplace.I_moment(irf[:, 0], irf[:, 1], int(m), int(n), u_lower=int(lo), u_upper=int(hi), u_spacing=int(nu))
         assert got == pytest.approx(ref, rel=1e-12, abs=1e-300), (m, n, nu, got, ref)
     assert laplace.I_moment(irf[:, 0], irf[:, 1], 5, 1) == pytest.approx(h["moment_vals"][1], rel=1e-12)  # default spacing
+    # y[m+1-u_upper] with a negative index wraps around as numpy does
+    for (m, n, lo, hi, nu), ref in zip(h["moment_wrap_cases"], h["moment_wrap_vals"]):
+        got = laplace.I_moment(irf[:, 0], irf[:, 1], int(m), int(n), u_lower=int(lo), u_upper=int(hi), u_spacing=int(nu))
+        assert got == pytest.approx(ref, rel=1e-12, abs=1e-300), (m, n, lo, hi, nu, got, ref)
     with pytest.raises(ValueError):
         laplace.I_moment(irf[:, 0], irf[:, 1], 500, 1)  # IndexError in the reference: lag beyond the IRF
+    with pytest.raises(ValueError):
+        laplace.I_moment(irf[:, 0], irf[:, 1], 0, 1, u_upper=500)  # ... and below -len(y)
 
 
 @pytest.mark.gpu

@@ -111,3 +111,37 @@ def test_eval_trial_move_matches_reference(which):
     pins = {"base": -59340.105083 - 32560.139058, "cutoff": -45982, "scale": 0, "mixed": -59340.105083 - 517.98}
     if which in pins:
         np.testing.assert_almost_equal(logll, pins[which], decimal=0)
+
+
+def _fittable_setup(mode):
+    """tests/golden/eval_fittable.npz: fittable fluences / absorptions (trial_move_evaluation.py:38-52) on a
+    density-mode and on a fluence-mode ensemble of two measurements."""
+    ev = np.load(os.path.join(G, "eval_fittable.npz"))
+    names = [str(x) for x in ev["names"]]
+    idx = {n: names.index(n) for n in names}
+    t_end, nt = ev["t_end_nt"]
+    times = [np.linspace(0, t_end, int(nt) + 1)] * 2
+    shared = {"units": ev[mode + "__units"], "solver": ("solveivp",), "model": "std", "hmax": 4, "rtol": 1e-7,
+              "atol": 1e-10, "_sim_info": {"lengths": [500, 500], "nx": [64, 64], "meas_types": ["TRPL", "TRPL"],
+                                           "num_meas": 2},
+              "_param_indexes": idx, "_init_params": np.array(ev[mode + "__ini"], copy=True), "ini_mode": mode,
+              "_times": times, "_vals": list(ev[mode + "__vals"]), "_uncs": list(ev[mode + "__uncs"]),
+              "fittable_fluences": (0.02, [int(m) for m in ev["ff_meas"]], []),
+              "fittable_absps": (0.02, [int(m) for m in ev["fa_meas"]], [tuple(int(x) for x in g) for g in ev["fa_groups"]])}
+    return ev, ev[mode + "__state"], {"model_uncertainty": {"TRPL": 1.0}, "_T": 1.0}, shared
+
+
+@pytest.mark.parametrize("mode", ["density", "fluence"])
+def test_eval_trial_move_fittable_factors_match_reference(mode):
+    """The factors scale elements 0 / 1 of the init-params row in BOTH ini_modes (trial_move_evaluation.py:44,:51):
+    in density mode that is the density of nodes 0 and 1."""
+    ev, state, uniq, shared = _fittable_setup(mode)
+    logll, table = O.eval_trial_move(state, uniq, shared, temperatures=[1.0, 3.0, 7.5])
+    # fluence mode: exp() of the Beer-Lambert profile differs by an ulp between libm and numpy, LSODA at rtol 1e-7
+    # then takes a different step sequence (4.7e-7 on the log-likelihood; the converged value is 1.3e-6 away)
+    tol = 1e-9 if mode == "density" else 2e-6
+    np.testing.assert_allclose(logll, float(ev[mode + "__logll_T1"]), rtol=tol)
+    np.testing.assert_allclose(table, ev[mode + "__ll_meas"], rtol=tol)
+    # the oracle scales a copy; the reference left its shared row scaled
+    np.testing.assert_array_equal(shared["_init_params"], ev[mode + "__ini"])
+    assert not np.array_equal(ev[mode + "__ini_after"], ev[mode + "__ini"])
