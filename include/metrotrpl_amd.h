@@ -199,6 +199,12 @@ int mtrpl_calculate_photoc(mtrpl_ctx *ctx, int64_t n, const double *N, const dou
 int mtrpl_newton_probe(mtrpl_ctx *ctx, int64_t B, int32_t nx, const double *par, const double *dx,
                        const double *c, const double *y, const double *b, double *x);
 
+/* ---- test entry: the controller's merged fp32 wave reductions -------------- */
+/* in: [B][4][64] floats (4 per-lane quantities of one wavefront); out: [B][7] = sum of row 0 through the one-sum
+ * ladder, of rows 0,1 through the two-sum ladder, of rows 0..3 through the four-sum ladder (DPP quad / row
+ * steps + the two permlane swaps of gfx950).  The error norms of the integrator go through these. */
+int mtrpl_reduce_probe(mtrpl_ctx *ctx, int64_t B, const float *in, float *out);
+
 /* ---- a10: IRF moment tables (laplace.py:13-41, :129-167) ---------------- */
 /* irf_t, irf_y: [nk]; table: [nk,3] (last row zero). */
 int mtrpl_make_I_table(mtrpl_ctx *ctx, int32_t nk, const double *irf_t, const double *irf_y,

@@ -95,16 +95,15 @@ struct TeamBackend {
     }
 
     // ---- whole-grid primitives ----
-    __device__ inline void publish(const real (&)[V], const real (&)[R]) {}
-    // sums over all threads of the team; every thread gets bitwise the same result
+    // fp32 sums over all threads of the team (they only steer the controller); every thread gets bitwise the
+    // same result
     template <int NS>
-    __device__ inline void reduce(real (&s)[NS], const real (&)[V], const real (&)[R])
+    __device__ inline void reduce_f(float (&s)[NS])
     {
         static_assert(NS <= 4, "rbuf holds 4 sums per wave");
-#pragma unroll
-        for (int k = 0; k < NS; ++k) s[k] = wave_sum_ctl(s[k]);
+        wave_sums_f<NS>(s, lane);
         if (W == 1) return;
-        real *r = rbuf + rpar * (4 * W);
+        float *r = reinterpret_cast<float *>(rbuf + rpar * (4 * W));
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) r[k * W + wave] = s[k];
@@ -112,7 +111,7 @@ struct TeamBackend {
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
-            real a = (real)0;
+            float a = 0.0f;
 #pragma unroll
             for (int w_ = 0; w_ < W; ++w_) a += r[k * W + w_];
             s[k] = a;
@@ -146,10 +145,10 @@ struct TeamBackend {
         return v;
     }
     __device__ inline void out_begin(double *o, double min_y, double scale, double deep) { em.begin(o, min_y, scale, deep); }
-    __device__ inline bool deep() const { return em.deep; }
-    __device__ inline void out_sample(int k, real partial)
+    __device__ inline bool deep() const { return em.deep != 0; }
+    __device__ inline real team_sum(real partial)
     {
-        // full-precision sum (reduce() is the controller-grade one)
+        // full-precision sum (reduce_f() is the controller-grade one)
         real s = wave_sum(partial);
         if (W > 1) {
             real *r = rbuf + rpar * (4 * W);
@@ -160,9 +159,10 @@ struct TeamBackend {
             for (int w_ = 0; w_ < W; ++w_) s += r[w_];
             rpar ^= 1;
         }
-        em.put(k, (double)s, (double)p.dx, tid == 0);
+        return s;
     }
-    __device__ inline void out_finish() {}
+    __device__ inline void out_first(real partial) { em.first((double)team_sum(partial), (double)p.dx, tid == 0); }
+    __device__ inline void out_sample(int k, real partial) { em.put(k, (double)team_sum(partial), (double)p.dx, tid == 0); }
 
     __device__ inline void put(int b, const M2r &m) const
     {
@@ -240,7 +240,7 @@ struct TeamBackend {
     }
 
     // ---- Newton matrix factors ----
-    __device__ inline void build(const real (&y_in)[V], real c, real)
+    __device__ inline void build(const real (&y_in)[V], real c)
     {
         real y[V];
 #pragma unroll

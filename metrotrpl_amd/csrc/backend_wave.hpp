@@ -84,22 +84,20 @@ struct WaveBackendT {
     }
 
     // ---- whole-grid primitives: everything is inside one wave ----
-    __device__ inline void publish(const double (&)[V], const double (&)[R]) {}
     template <int NS>
-    __device__ inline void reduce(double (&s)[NS], const double (&)[V], const double (&)[R])
-    {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) s[k] = uniform(wave_sum_ctl(s[k]));
-    }
+    __device__ inline void reduce_f(float (&s)[NS]) { wave_sums_f<NS>(s, lane); }
     __device__ inline double scan_excl(double run) const { return wave_scan_incl(run, lane) - run; }
     __device__ inline double max_all(double v) const { return wave_max(v); }
     __device__ inline void out_begin(double *o, double min_y, double scale, double deep) { em.begin(o, min_y, scale, deep); }
-    __device__ inline bool deep() const { return em.deep; }
+    __device__ inline bool deep() const { return em.deep != 0; }
+    __device__ inline void out_first(double partial) { em.first(uniform(wave_sum(partial)), p.dx, lane == 0); }
     __device__ inline void out_sample(int k, double partial) { em.put(k, uniform(wave_sum(partial)), p.dx, lane == 0); }
-    __device__ inline void out_finish() {}
 
     // ---- RHS: forward_solver.py:332-372 (dydt_numba) ----
-    // Padded nodes (i >= L) carry N=P=1, E=0 and get f=0.
+    // Padded nodes (i >= L) carry N=P=1, E=0 for ever (integrate() gives them a zero step): an edge between two
+    // of them has exactly zero flux, the edge between the last real node and the first padded one is the back
+    // surface for the real node and garbage for the padded one, whose f is never looked at.  So nothing is masked
+    // here but the two surfaces.
     __device__ inline void rhs(const double (&y)[V], double (&f)[V]) const
     {
         double Jn[R + 1], Jp[R + 1];
@@ -113,12 +111,11 @@ struct WaveBackendT {
             const double Pm = (r == 0) ? Pl : y[R + ((r == 0) ? 0 : r - 1)];
             double jn, jp;
             edge_flux(p, Nm, N, Pm, P, E, jn, jp);  // :356-359
-            if (i == 0) {  // :346-351
+            if (r == 0) {  // :346-351 (lane 0 only)
                 const double Sft = surface_term(p, p.Sf, N, P);
-                jn = Sft;
-                jp = -Sft;
+                jn = (i == 0) ? Sft : jn;
+                jp = (i == 0) ? -Sft : jp;
             }
-            if (i >= L) { jn = 0.0; jp = 0.0; }
             Jn[r] = jn;
             Jp[r] = jp;
         }
@@ -136,15 +133,14 @@ struct WaveBackendT {
                 jpr = Sbt;
             }
             const double recomb = bulk_recomb(p, N, P, NP);  // :366
-            const bool real_ = i < L;
-            f[r] = real_ ? ((jnr - Jn[r]) * p.idx - recomb) : 0.0;       // :369
-            f[R + r] = real_ ? (-(jpr - Jp[r]) * p.idx - recomb) : 0.0;  // :370
-            f[2 * R + r] = (real_ && i > 0) ? (-(Jn[r] + Jp[r]) * p.Lam) : 0.0;  // :363 (edge 0: exactly 0)
+            f[r] = (jnr - Jn[r]) * p.idx - recomb;       // :369
+            f[R + r] = -(jpr - Jp[r]) * p.idx - recomb;  // :370
+            f[2 * R + r] = -(Jn[r] + Jp[r]) * p.Lam;     // :363 (edge 0: Sft - Sft, exactly 0)
         }
     }
 
     // ---- factorisation of M = I - c*J(yJ) ----
-    __device__ inline void build(const double (&y_in)[V], double c, double)
+    __device__ inline void build(const double (&y_in)[V], double c)
     {
         double y[V];
 #pragma unroll
@@ -314,8 +310,12 @@ struct WaveBackendT {
     {
         if constexpr (F32BLK) {
             apply_f32(b, x);
-            return;
+        } else {
+            apply_f64(b, x);
         }
+    }
+    __device__ inline void apply_f64(const double (&b)[V], double (&x)[V])
+    {
         // E-elimination right-hand side
         V2 wb[3];
         wb[0] = V2{w[0][0] * b[4], w[0][1] * b[4]};

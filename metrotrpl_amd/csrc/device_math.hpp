@@ -118,10 +118,56 @@ template <class T> __device__ inline T wave_sum(T v)
     v += dpp0<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
     return lane_value(v, 63);
 }
-// The same in f32 for quantities that only steer the controller (error norms): the DPP move folds into
-// the add (v_add_f32_dpp), a third of the instructions of the f64 ladder.
-__device__ inline double wave_sum_ctl(double v) { return (double)wave_sum((float)v); }
-__device__ inline float wave_sum_ctl(float v) { return wave_sum(v); }
+// Several fp32 sums over the 64 lanes in ONE DPP ladder (the sums only steer the controller).  The first
+// level(s) add neighbours inside a quad and keep a different sum per lane of the quad (lane & 1 selects between
+// two sums, lane & 3 between four), the row_shr levels then work on stride-2 / stride-4 lanes, and the rows are
+// combined with the two permlane swaps of gfx950: about half the instructions of one ladder per sum, and no
+// serial chain of six dependent DPP adds per sum.  Results are wave-uniform (SGPRs).
+template <int CTRL> __device__ inline float add_dpp(float v)  // v + dpp(v), sources out of range read as 0
+{
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ inline float rows_total(float v)  // every lane <- sum over the 4 rows of the same lane-in-row
+{
+    // (the two results are copied to scalars before the bit cast: __builtin_bit_cast applied to an element of the
+    // returned vector reads element 0 for both with this compiler)
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // rows (0,0,2,2) | (1,1,3,3)
+    const unsigned a0 = a[0], a1 = a[1];
+    v = __builtin_bit_cast(float, a0) + __builtin_bit_cast(float, a1);
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);  // halves (lo,lo) | (hi,hi)
+    const unsigned b0 = b[0], b1 = b[1];
+    return __builtin_bit_cast(float, b0) + __builtin_bit_cast(float, b1);
+}
+template <int NS> __device__ inline void wave_sums_f(float (&s)[NS], int lane)
+{
+    static_assert(NS == 1 || NS == 2 || NS == 4, "1, 2 or 4 sums");
+    if constexpr (NS == 1) {
+        float v = s[0];
+        v = add_dpp<0x111>(v); v = add_dpp<0x112>(v); v = add_dpp<0x114>(v); v = add_dpp<0x118>(v);  // row_shr 1,2,4,8
+        s[0] = lane_value(rows_total(v), 15);
+    } else if constexpr (NS == 2) {
+        const float a = add_dpp<0xb1>(s[0]), b = add_dpp<0xb1>(s[1]);  // quad_perm [1,0,3,2]: pair sums
+        float v = (lane & 1) ? b : a;
+        v = add_dpp<0x112>(v); v = add_dpp<0x114>(v); v = add_dpp<0x118>(v);  // lanes 14 / 15 of a row: its two totals
+        v = rows_total(v);
+        s[0] = lane_value(v, 14);
+        s[1] = lane_value(v, 15);
+    } else {
+        const float a = add_dpp<0xb1>(s[0]), b = add_dpp<0xb1>(s[1]), c = add_dpp<0xb1>(s[2]), d = add_dpp<0xb1>(s[3]);
+        float ab = (lane & 1) ? b : a, cd = (lane & 1) ? d : c;
+        ab = add_dpp<0x4e>(ab);  // quad_perm [2,3,0,1]: quad sums, lane & 1 still selects the sum
+        cd = add_dpp<0x4e>(cd);
+        float v = (lane & 2) ? cd : ab;
+        v = add_dpp<0x114>(v); v = add_dpp<0x118>(v);  // lanes 12..15 of a row: its four totals
+        v = rows_total(v);
+        s[0] = lane_value(v, 12);
+        s[1] = lane_value(v, 13);
+        s[2] = lane_value(v, 14);
+        s[3] = lane_value(v, 15);
+    }
+}
 template <class T> __device__ inline T wave_max(T v)
 {
 #pragma unroll
@@ -140,21 +186,13 @@ template <class T> __device__ inline T wave_scan_incl(T v, int lane)
 }
 
 // ---- controller-grade transcendental shortcuts ---------------------------------------------------
-// Norms, contraction rates and step factors only steer the controller: f32 hardware
-// sqrt / rcp / log2 / exp2 (1 ulp of f32) replace the fp64 sequences on the scalar critical path.
-template <class T> __device__ inline T norm_sqrt(T x) { return (T)__builtin_amdgcn_sqrtf((float)x); }
-template <class T> __device__ inline T ctl_rcp(T x) { return (T)__builtin_amdgcn_rcpf((float)x); }
-// x^e (e = -1/k as a compile-time constant)
-template <class T> __device__ inline T pow_neg_inv(T x, float e)
+// Norms, contraction rates and step factors only steer the controller: they are fp32 values handled with the
+// hardware sqrt / rcp / log2 / exp2 (1 ulp of fp32).
+// x^e for x > 0
+__device__ inline float pow_ctl(float x, float e)
 {
-    const float xf = (float)fmin(fmax(x, (T)1e-30), (T)1e30);
-    return (T)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xf) * e);
-}
-// x^(-1/k)
-template <class T> __device__ inline T inv_root(T x, int k)
-{
-    const float xf = (float)fmin(fmax(x, (T)1e-30), (T)1e30);
-    return (T)__builtin_amdgcn_exp2f(-__builtin_amdgcn_logf(xf) / (float)k);
+    const float xf = fminf(fmaxf(x, 1e-30f), 1e30f);
+    return __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xf) * e);
 }
 
 // 1/x by the hardware seed + two Newton steps (~1 ulp; no div_scale/fixup ladder: operands here are

@@ -119,11 +119,8 @@ __device__ inline void rhs_probe(BK &bk, const double *par, const double *dxs, c
     const int L = nx, S = (BK::TRAPS ? 4 : 3) * nx + 1;
     const int oP = (BK::TRAPS ? 2 : 1) * L, oE = (BK::TRAPS ? 3 : 2) * L;
     bk.set_problem(make_par<double>(par + 16 * s, dxs[s]), L);
-    double yl[V], fl[V], zE[R];
+    double yl[V], fl[V];
     load_state(bk, y + s * S, L, yl, 1.0);
-#pragma unroll
-    for (int r = 0; r < R; ++r) zE[r] = 0.0;
-    bk.publish(yl, zE);
     bk.rhs(yl, fl);
     double *fs = dy + s * S;
 #pragma unroll
@@ -168,16 +165,13 @@ __device__ inline void newton_probe(BK &bk, const double *par, const double *dxs
     constexpr int R = BK::R, V = BK::V;
     const int L = nx, S = 3 * nx + 1;
     bk.set_problem(make_par<double>(par + 16 * s, dxs[s]), L);
-    double yl[V], bl[V], xl[V], zE[R];
+    double yl[V], bl[V], xl[V];
     load_state(bk, y + s * S, L, yl, 1.0);
     load_state(bk, b + s * S, L, bl, 0.0);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < R; ++r)
         if (bk.node(r) == 0) bl[2 * R + r] = 0.0;  // the E_0 row of I - cJ is an identity row
-        zE[r] = -bl[2 * R + r];  // with h = 0 the neighbouring group reads b_E of its boundary edge from here
-    }
-    bk.publish(yl, zE);
-    bk.build(yl, cs[s], 0.0);
+    bk.build(yl, cs[s]);
     bk.apply(bl, xl);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -201,6 +195,24 @@ __global__ __launch_bounds__(64) void newton_probe_kernel_wave(const double *par
     WaveBackendT<F32BLK> bk(threadIdx.x, fac_lds);
     newton_probe(bk, par, dxs, cs, y, b, x, nx, s);
 }
+// the controller's merged fp32 wave reductions (device_math.hpp: wave_sums_f) on caller data: in [B][4][64], out [B][7] =
+// the sum of row 0 through the 1-sum ladder, of rows 0-1 through the 2-sum ladder, of rows 0-3 through the 4-sum ladder
+__global__ __launch_bounds__(64) void reduce_probe_kernel(const float *in, float *out, int64_t B)
+{
+    const int64_t s = blockIdx.x;
+    if (s >= B) return;
+    const int lane = threadIdx.x;
+    const float *q = in + s * 256;
+    float s1[1] = {q[lane]}, s2[2] = {q[lane], q[64 + lane]}, s4[4] = {q[lane], q[64 + lane], q[128 + lane], q[192 + lane]};
+    wave_sums_f<1>(s1, lane);
+    wave_sums_f<2>(s2, lane);
+    wave_sums_f<4>(s4, lane);
+    if (lane == 0) {
+        float *o = out + s * 7;
+        o[0] = s1[0]; o[1] = s2[0]; o[2] = s2[1]; o[3] = s4[0]; o[4] = s4[1]; o[5] = s4[2]; o[6] = s4[3];
+    }
+}
+
 // forward_solver.py:26-38: one wave per row, any nx (chunked inclusive scan)
 __global__ __launch_bounds__(64) void e_field_kernel(const double *N, const double *P, double *E, int nx, int64_t rows,
                                                      double n0, double p0, double pref, double corner_E)
@@ -644,6 +656,24 @@ int mtrpl_newton_probe(mtrpl_ctx *ctx, int64_t B, int32_t nx, const double *par,
     return MTRPL_OK;
 }
 
+int mtrpl_reduce_probe(mtrpl_ctx *ctx, int64_t B, const float *in, float *out)
+{
+    if (!ctx) return MTRPL_ERR_BAD_ARG;
+    if (B <= 0) return MTRPL_OK;
+    if (!in || !out) return bad(ctx, MTRPL_ERR_BAD_ARG, "bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf di(ctx, 0), dout(ctx, 1);
+    HIP_TRY(ctx, di.alloc(sizeof(float) * 256 * B));
+    HIP_TRY(ctx, dout.alloc(sizeof(float) * 7 * B));
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(di.p, in, sizeof(float) * 256 * B, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(reduce_probe_kernel, dim3((unsigned)B), dim3(64), 0, s, di.as<float>(), dout.as<float>(), B);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, sizeof(float) * 7 * B, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return MTRPL_OK;
+}
+
 int mtrpl_E_field(mtrpl_ctx *ctx, int64_t rows, int32_t nx, const double *N, const double *P, double n0, double p0,
                   double eps, double dx, double corner_E, double *E)
 {
@@ -738,5 +768,16 @@ int mtrpl_calculate_photoc(mtrpl_ctx *ctx, int64_t n, const double *N, const dou
 }
 
 #include "irf_capi.inc"
+
+#ifdef MTRPL_TRACE
+extern "C" int mtrpl_debug_trace(float *out, int *n)
+{
+    hipMemcpyFromSymbol(n, HIP_SYMBOL(mtrpl::g_trace_n), sizeof(int));
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(mtrpl::g_trace), sizeof(float) * 8 * 8192);
+    int zero = 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(mtrpl::g_trace_n), &zero, sizeof(int));
+    return 0;
+}
+#endif
 
 }  // extern "C"

@@ -15,20 +15,24 @@
 //   BK::real, BK::R (nodes per thread), BK::V (values per thread = 3R std / 4R traps), BK::TRAPS
 //   bk.set_problem(par, L)          model parameters and grid size of this solve
 //   bk.node(r)                      global node index of slot r of this thread
-//   bk.publish(y, zE)               make this thread group's boundary state (y and, per node slot, zE = z1_E + acor_E)
-//                                   visible to rhs()/build()/apply()
-//                                   of the neighbouring group (no-op where shuffles reach everything)
-//   bk.rhs(y, f)                    f = dy/dt                              (forward_solver.py:332-418)
-//   bk.build(y, c, h)               factorise I - c*J(y)
+//   bk.rhs(y, f)                    f = dy/dt (forward_solver.py:332-418); padded slots (node >= L) may
+//                                   hold anything finite: integrate() multiplies them by a zero step
+//   bk.build(y, c)                  factorise I - c*J(y)
 //   bk.apply(b, x)                  x = (I - c*J)^-1 b with the kept factors
-//   bk.reduce<NS>(s, y, zE)         s[k] <- sum over the whole grid, identical in every thread;
-//                                   doubles as publish(y, zE) for the next rhs()
+//   bk.reduce_f<NS>(s)              s[k] <- sum over the whole grid in fp32 (the sums only steer the
+//                                   controller), identical in every thread
 //   bk.scan_excl(v), bk.max_all(v)  exclusive prefix over the threads before this one / maximum
-//   bk.out_begin / out_sample / out_finish   emission of the output samples (scale, min_y clamp)
+//   bk.out_begin / out_first / out_sample / deep   emission of the output samples (scale, min_y clamp)
 //   bk.leader()                     the one thread that writes status / stats
 //
 // Value layout of a thread: y[r] = N, y[R+r] = P, y[2R+r] = E on the left face of node r,
 // y[3R+r] = N_trap (traps model).
+//
+// What is wave-uniform and only steers the integration -- error norms, Newton contraction rates, step and
+// order factors -- is fp32 throughout (`ctl`): there is no scalar floating point on this ISA, so each such
+// operation is a vector instruction with one useful lane, and a conversion to and from fp64 around every
+// hardware sqrt / rcp / log / exp tripled their number.  Everything order-dependent comes from one 128-byte row
+// of a table in constant memory (scalar loads), not from a switch over the order.
 #pragma once
 #include "model_physics.hpp"
 
@@ -46,20 +50,16 @@
 #define MTRPL_STAMP(acc) do { } while (0)
 #endif
 
-// `order` is wave-uniform.  The Nordsieck rows above the current order are kept at exactly zero, so every
-// VECTOR operation on the history (Pascal predictor, retraction, rescaling, Horner interpolation) is the
-// order-5 one whatever the order is -- one body, no joins of 36-register arrays behind a five-way switch --
-// and the order only selects SCALAR coefficients, through this switch:
-#define MTRPL_ORDER_SWITCH(order_, CALL)               \
-    switch (order_) {                                   \
-        case 1: { constexpr int K = 1; CALL; } break;   \
-        case 2: { constexpr int K = 2; CALL; } break;   \
-        case 3: { constexpr int K = 3; CALL; } break;   \
-        case 4: { constexpr int K = 4; CALL; } break;   \
-        default: { constexpr int K = 5; CALL; } break;  \
-    }
-
 namespace mtrpl {
+
+#ifdef MTRPL_TRACE
+__device__ float g_trace[8 * 8192];
+__device__ int g_trace_n;
+#define TRACE(code, n_iter_, dsm_) do { if (sidx == MTRPL_TRACE && bk.leader() && g_trace_n < 8192) { float *q_ = g_trace + 8 * g_trace_n++; \
+    q_[0] = (float)(code); q_[1] = (float)t; q_[2] = (float)h; q_[3] = (float)order; q_[4] = (float)(n_iter_); q_[5] = (float)(dsm_); q_[6] = (float)n_equal; q_[7] = (float)io; } } while (0)
+#else
+#define TRACE(code, n_iter_, dsm_) do { } while (0)
+#endif
 
 struct SolveTuning {
     double rtol_scale;  // internal rtol = min(rtol_cap, rtol_scale * desc.rtol), then the policy factors below
@@ -108,14 +108,23 @@ struct DefaultTune {
     }
 };
 
-// ODEPACK cfode, meth = 2: l-vector and error-test constants of the fixed-step BDF of order Q
-struct NqTable {
-    double el[6][6];   // el[q][j], q = 1..5
-    double t1[6], t2[6], t3[6];
+// ODEPACK cfode, meth = 2: l-vector and error-test constants of the fixed-step BDF of order q = 1..5, one
+// 128-byte row per order.  The rows sit in constant memory: the order is wave-uniform, so a row is read with
+// scalar loads where it is needed and no order-dependent constant lives across a step.
+struct NqRow {
+    double el[6];       // l-vector, zero above the order
+    double inv_t1, inv_t2, inv_t3;  // 1 / error-test constants for order q-1, q, q+1 (stode's tesco)
+    double el_up;       // l_q / (q+1): the new last row on an order increase
+    double elK;         // l_q: coefficient of the last row
+    float nik0, nik1, nik2;         // -1/q, -1/(q+1), -1/(q+2): exponents of the three step factors
+    float inv_qp1;                  // 1/(q+1)
+    double pad_[3];
 };
-constexpr NqTable nq_make_table()
+static_assert(sizeof(NqRow) == 128, "one row = 128 bytes");
+struct NqRows { NqRow row[6]; };
+constexpr NqRows nq_make_rows()
 {
-    NqTable T{};
+    NqRows T{};
     double pc[8] = {1.0, 0, 0, 0, 0, 0, 0, 0};
     double rq1fac = 1.0;
     for (int nq = 1; nq <= 5; ++nq) {
@@ -123,24 +132,20 @@ constexpr NqTable nq_make_table()
         pc[nq] = 0.0;
         for (int i = nq; i >= 1; --i) pc[i] = pc[i - 1] + fnq * pc[i];
         pc[0] = fnq * pc[0];
-        for (int j = 0; j <= nq; ++j) T.el[nq][j] = pc[j] / pc[1];
-        T.el[nq][1] = 1.0;
-        T.t1[nq] = rq1fac;
-        T.t2[nq] = (double)(nq + 1) / T.el[nq][0];
-        T.t3[nq] = (double)(nq + 2) / T.el[nq][0];
+        NqRow &r = T.row[nq];
+        for (int j = 0; j <= nq; ++j) r.el[j] = pc[j] / pc[1];
+        r.el[1] = 1.0;
+        const double t1 = rq1fac, t2 = (double)(nq + 1) / r.el[0], t3 = (double)(nq + 2) / r.el[0];
+        r.inv_t1 = 1.0 / t1; r.inv_t2 = 1.0 / t2; r.inv_t3 = 1.0 / t3;
+        r.elK = r.el[nq];
+        r.el_up = r.el[nq] / (double)(nq + 1);
+        r.nik0 = -1.0f / (float)nq; r.nik1 = -1.0f / (float)(nq + 1); r.nik2 = -1.0f / (float)(nq + 2);
+        r.inv_qp1 = 1.0f / (float)(nq + 1);
         rq1fac = rq1fac / fnq;
     }
     return T;
 }
-template <int K>
-struct NqC {
-    static constexpr NqTable T = nq_make_table();
-    static constexpr double el0 = T.el[K][0];
-    static constexpr double elK = T.el[K][K];  // coefficient of the last row
-    static constexpr double inv_t1 = 1.0 / T.t1[K], inv_t2 = 1.0 / T.t2[K], inv_t3 = 1.0 / T.t3[K];
-    static constexpr double el_up = T.el[K][K] / (double)(K + 1);  // new last row on an order increase
-    static constexpr float nik0 = -1.0f / (float)K, nik1 = -1.0f / (float)(K + 1), nik2 = -1.0f / (float)(K + 2);
-};
+static __constant__ NqRows kNq = nq_make_rows();
 
 // z <- A z (Pascal triangle), in place; and its inverse
 template <int K, int V, class T>
@@ -163,25 +168,6 @@ __device__ inline void nq_retract(T (&z)[6][V])
 #pragma unroll
             for (int v = 0; v < V; ++v) z[j - 1][v] -= z[j][v];
 }
-// z[j] += l_j * acor
-template <int K, int V, class T>
-__device__ inline void nq_correct(T (&z)[6][V], const T (&acor)[V])
-{
-    constexpr NqTable Tb = nq_make_table();
-#pragma unroll
-    for (int j = 0; j <= K; ++j)
-#pragma unroll
-        for (int v = 0; v < V; ++v) z[j][v] += (T)Tb.el[K][j] * acor[v];
-}
-// the same with the l-vector of a run-time order (zero above it): rows above the order stay zero
-template <int V, class T>
-__device__ inline void nq_correct_rt(T (&z)[6][V], const T (&acor)[V], const T (&el)[6])
-{
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-#pragma unroll
-        for (int v = 0; v < V; ++v) z[j][v] += el[j] * acor[v];
-}
 // z[j] *= eta^j
 template <int K, int V, class T>
 __device__ inline void nq_rescale(T (&z)[6][V], T eta)
@@ -194,38 +180,34 @@ __device__ inline void nq_rescale(T (&z)[6][V], T eta)
         for (int v = 0; v < V; ++v) z[j][v] *= r;
     }
 }
-// y(t_n + s h) = sum_j z[j] s^j
-template <int K, int V, class T>
-__device__ inline void nq_dense(const T (&z)[6][V], T s, T (&yq)[V])
-{
-#pragma unroll
-    for (int v = 0; v < V; ++v) yq[v] = z[K][v];
-#pragma unroll
-    for (int j = K - 1; j >= 0; --j)
-#pragma unroll
-        for (int v = 0; v < V; ++v) yq[v] = yq[v] * s + z[j][v];
-}
 
 // Output samples: unit scale (forward_solver.py:189,:197) and the min_y clamp "from the first sample
 // below min_y onward" (:190-192).  One instance per solve, held by the thread(s) that store.
 struct Emitter {
     double *o;
     double min_y, scale;
-    double deep_below;  // deep_frac x the first sample
-    bool clamped, deep;
+    double deep_below;  // deep_frac x |first sample|
+    int clamped, deep;
     __device__ inline void begin(double *o_, double min_y_, double scale_, double deep_frac)
     {
-        o = o_; min_y = min_y_; scale = scale_; clamped = false; deep = false;
-        deep_below = -deep_frac;  // negative until the first sample fixes the scale
+        o = o_; min_y = min_y_; scale = scale_; clamped = 0; deep = 0;
+        deep_below = deep_frac;
     }
     // total = dx-less grid sum; writer = this thread stores.  Every thread that calls sees the same v,
     // so `deep` is uniform among the callers.
+    __device__ inline void first(double total, double dx, bool writer)
+    {
+        double v = total * dx * scale;
+        deep_below = deep_below * fabs(v);  // the first sample fixes the scale
+        clamped = v < min_y;
+        if (clamped) v = min_y;
+        if (writer) o[0] = v;
+    }
     __device__ inline void put(int k, double total, double dx, bool writer)
     {
         double v = total * dx * scale;
-        if (deep_below < 0.0) deep_below = -deep_below * fabs(v);
-        else if (!(fabs(v) >= deep_below)) deep = true;
-        if (!clamped && v < min_y) clamped = true;
+        deep |= !(fabs(v) >= deep_below);
+        clamped |= v < min_y;
         if (clamped) v = min_y;
         if (writer) o[k] = v;
     }
@@ -241,6 +223,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
     const unsigned long long sched_t0_ = __builtin_amdgcn_s_memrealtime();
 #endif
     using real = typename BK::real;
+    using ctl = float;  // wave-uniform controller arithmetic
     constexpr int R = BK::R, V = BK::V;
     constexpr bool TRAPS = BK::TRAPS;
     const int L = ds.nx, nt = ds.nt, meas = ds.meas;
@@ -249,8 +232,9 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
     const ParT<real> &p = bk.p;
     const double *ts = tsteps + ds.t_off;
     const real hmax = tune.honor_hmax ? (real)ds.hmax : big<real>();
-    const real inv_S = (real)(1.0 / (double)((TRAPS ? 4 : 3) * L + 1));
+    const ctl inv_S = (ctl)(1.0 / (double)((TRAPS ? 4 : 3) * L + 1));
     bk.out_begin(out + ds.out_off, ds.min_y, (meas == MTRPL_MEAS_TRPL) ? 1e23 : 1e9, tune.hmax_deep);  // forward_solver.py:189,:197
+    const int lane64 = (int)(threadIdx.x & 63);
 
     // ---- initial condition, forward_solver.py:100-122 ----
     real y[V];
@@ -334,48 +318,66 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
     // accumulated, so it gets a looser relative weight than the densities (DESIGN.md "error control")
     // (TRPL only: the photoconductivity weighs dP directly, and its p99 census error doubles with a looser field)
     const real rtol_E = rtol * ((meas == MTRPL_MEAS_TRPL) ? (real)tune.e_weight : (real)1);
-    auto rtol_of = [&](int v) { return (v >= 2 * R && v < 3 * R) ? rtol_E : rtol; };
-    auto atol_of = [&](int v) { return (v >= 2 * R && v < 3 * R) ? atol_E : atol; };
+    auto is_E = [](int v) { return v >= 2 * R && v < 3 * R; };
+    auto rtol_of = [&](int v) { return is_E(v) ? rtol_E : rtol; };
+    auto atol_of = [&](int v) { return is_E(v) ? atol_E : atol; };
+    // the same as fp32 weights 1/(atol + rtol |y|) are built from.  Relative to the largest initial density so
+    // that atol (1e-21 nm^-3 and below) and the densities stay far inside the fp32 range.
+    const ctl rtol_f = (ctl)rtol, rtol_E_f = (ctl)rtol_E, atol_f = (ctl)atol, atol_E_f = (ctl)atol_E;
     const real early_until = (nt > 1) ? (real)(tune.early_frac * ts[1]) : (real)0;
-    const real early_inv = (real)(1.0 / fmax(tune.early_factor, 1.0));
-    const real newton_tol = (tune.newton_tol > 0.0)
-                                ? (real)tune.newton_tol
-                                : (real)fmax(10.0 * 2.220446049250313e-16 / (double)rtol, fmin(0.03, sqrt((double)rtol)));
+    const ctl early_mul = (ctl)(1.0 / fmax(tune.early_factor, 1.0));  // norms of an early step are scaled by this
+    const ctl newton_tol = (tune.newton_tol > 0.0)
+                               ? (ctl)tune.newton_tol
+                               : (ctl)fmax(10.0 * 2.220446049250313e-16 / (double)rtol, fmin(0.03, sqrt((double)rtol)));
 
-    int n_steps = 0, n_rhs = 0, n_fac = 0, n_jac = 0, n_rej = 0, n_nfail = 0;
+    int n_steps = 0, n_rhs = 0, n_fac = 0, n_bad = 0;  // n_bad: rejected steps | Newton failures << 16
     int st = MTRPL_SOLVE_OK;
 
     // dx-less grid sum of the signal density of one state
-    auto sig_partial = [&](const real (&yy)[V]) {
+    auto sig_partial = [&](const real (&nn)[R], const real (&pp)[R]) {
         real s = (real)0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const real v = signal_density(p, meas, yy[r], yy[R + r]);
+            const real v = signal_density(p, meas, nn[r], pp[r]);
             s += (bk.node(r) < L) ? v : (real)0;
         }
         return s;
     };
-    bk.out_sample(0, sig_partial(y));
+    {
+        real nn[R], pp[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { nn[r] = y[r]; pp[r] = y[R + r]; }
+        bk.out_first(sig_partial(nn, pp));
+    }
 
     real z[6][V];
-    real f[V], w[V], zE[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) zE[r] = (real)0;
-    bk.publish(y, zE);
+    real f[V];
     bk.rhs(y, f);
     n_rhs++;
+#pragma unroll
+    for (int v = 0; v < V; ++v) f[v] = (bk.node(v % R) < L) ? f[v] : (real)0;  // padded slots: rhs() leaves anything
 
     // ---- initial step (Hairer, Norsett & Wanner I, II.4, first-order variant) ----
     real h;
     {
-        real s3[1];
+        // weighted RMS norm; scaled by its largest entry so that the fp32 sum of squares cannot overflow
         auto tnorm = [&](const real (&vv)[V]) {
-            s3[0] = (real)0;
+            real m = (real)0;
 #pragma unroll
-            for (int k = 0; k < V; ++k) s3[0] += vv[k] * vv[k];
-            bk.template reduce<1>(s3, y, zE);
-            return norm_sqrt(s3[0] * inv_S);
+            for (int k = 0; k < V; ++k) m = fmax(m, fabs(vv[k]));
+            m = bk.max_all(m);
+            if (!(m > (real)0) || !(m < big<real>())) return m;
+            const real im = (real)1 / m;
+            float s1[1] = {0.0f};
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float q_ = (float)(vv[k] * im);
+                s1[0] = fmaf(q_, q_, s1[0]);
+            }
+            bk.template reduce_f<1>(s1);
+            return m * (real)__builtin_amdgcn_sqrtf(s1[0] * inv_S);
         };
+        real w[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) w[v] = y[v] / (atol_of(v) + rtol_of(v) * fabs(y[v]));
         const real d0 = tnorm(w);
@@ -386,11 +388,11 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         real y1[V], f1[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) y1[v] = y[v] + h0 * f[v];
-        bk.publish(y1, zE);
         bk.rhs(y1, f1);
         n_rhs++;
 #pragma unroll
-        for (int v = 0; v < V; ++v) w[v] = (f1[v] - f[v]) / (atol_of(v) + rtol_of(v) * fabs(y[v]));
+        for (int v = 0; v < V; ++v)
+            w[v] = (bk.node(v % R) < L) ? (f1[v] - f[v]) / (atol_of(v) + rtol_of(v) * fabs(y[v])) : (real)0;
         const real d2 = tnorm(w) / h0;
         const real dm = fmax(d1, d2);
         const real h1 = (dm <= (real)1e-15) ? fmax((real)1e-6, h0 * (real)1e-3) : (real)sqrt((real)0.01 / dm);
@@ -406,230 +408,264 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
 
     int order = 1, n_equal = 0;
     real t = (real)0;
-    n_jac++;
-    bool have_fac = false;
-    real rate_prev = (real)1;
+    int have_fac = 0;
+    ctl rate_prev = 1.0f;
     int rate_age = 0;
-    int io = 1;
-    real tq_next = (nt > 1) ? (real)ts[1] : big<real>();
     int since_rej = 1000;  // accepted steps since the last rejected one
-    real acp[V];           // the correction of the previous step (order-increase estimate)
+    int fails = 0;         // attempts in a row that did not end in an accepted step
+    float acp[V];          // the correction of the previous step (order-increase estimate), fp32: it only enters a norm
 #pragma unroll
-    for (int v = 0; v < V; ++v) acp[v] = (real)0;
+    for (int v = 0; v < V; ++v) acp[v] = 0.0f;
+
+    // The next 64 sample times sit in one register pair, lane k holding ts[io0 + k]: a sample time reaches the
+    // scalar unit by v_readlane, and the scalar-memory load (with its wait on lgkmcnt, which the LDS traffic of
+    // the Newton solver shares) is gone from the dense-output loop.
+    int io = 1, io0 = 1;
+    double tsv = (io0 + lane64 < nt) ? ts[io0 + lane64] : 1e300;
+    real tq_next = (nt > 1) ? (real)lane_value(tsv, 0) : big<real>();
 
 #ifdef MTRPL_STAMPS
-    // controller vector work | factorisation | rhs | linear re-solve | reductions + publishes | Newton glue | dense output
+    // controller vector work | factorisation | rhs | linear re-solve | reductions | Newton glue | dense output
     unsigned long long tlast_ = __builtin_amdgcn_s_memtime(), ph_ctl = 0, ph_fac = 0, ph_rhs = 0, ph_app = 0,
                        ph_red = 0, ph_glue = 0, ph_dense = 0;
 #endif
+    // ---- one pass of this loop = one ATTEMPT at a step ----
     while (io < nt) {
         MTRPL_STAMP(ph_ctl);
-        if (n_steps >= tune.max_steps) { st = MTRPL_SOLVE_STOPPED_EARLY; break; }
-        bool accepted = false;
-        real acor[V], yn[V], isc[V];  // isc: 1/(atol + rtol*|y_predicted|), the error weights of this step
-        real dsm = (real)0, safety = (real)0.9;
-        real ssel0 = (real)0, ssel1 = (real)0;  // selection sums of the accepted iteration
-        int attempts = 0;
-        while (!accepted) {
-            if (++attempts > 60 || !(h > (real)1e-13 * fmax(t, (real)1e-3))) { st = MTRPL_SOLVE_STOPPED_EARLY; break; }
-            MTRPL_STAMP(ph_ctl);
-            // the order / step-size selection runs after this step if it is accepted with n_equal >= order:
-            // its two grid sums then travel with the Newton norms instead of costing a reduction of their own
-            const bool will_select = n_equal >= order;
-            // predictor: z <- A z; z[0] is the predicted state, z[1] the predicted h*y'
-            real el0 = (real)1, inv_t2 = (real)1, elK = (real)0;
-            nq_predict<5, V>(z);
-            MTRPL_ORDER_SWITCH(order, (el0 = (real)NqC<K>::el0, inv_t2 = (real)NqC<K>::inv_t2, elK = (real)NqC<K>::elK))
-            const real c = h * el0;
-            const real early_scale = (tune.early_factor > 1.0 && t + h <= early_until) ? early_inv : (real)1;
+        if (n_steps >= tune.max_steps || fails > 60 || !(h > (real)1e-13 * fmax(t, (real)1e-3))) {
+            st = MTRPL_SOLVE_STOPPED_EARLY;
+            break;
+        }
+        const NqRow &nq = kNq.row[order];
+        // the order / step-size selection runs after this step if it is accepted with n_equal >= order:
+        // its two grid sums then travel with the Newton norms instead of costing a reduction of their own
+        const bool will_select = n_equal >= order;
+        // predictor: z <- A z; z[0] is the predicted state, z[1] the predicted h*y'
+        nq_predict<5, V>(z);
+        const real el0 = (real)nq.el[0];
+        const real c = h * el0;
+        // steps that end before early_frac x the first sample time get early_factor x the local tolerance: the
+        // norms of such a step are scaled instead of its weights
+        const ctl nscale = (tune.early_factor > 1.0 && t + h <= early_until) ? early_mul : 1.0f;
+        // error weights of this step, 1/(atol + rtol |y_predicted|), fp32
+        float isc[V];
 #pragma unroll
-            for (int v = 0; v < V; ++v) isc[v] = ctl_rcp(atol_of(v) + rtol_of(v) * fabs(z[0][v])) * early_scale;
-            MTRPL_STAMP(ph_ctl);
-            // simplified Newton on acor:  (I - h l0 J) dx = h f(y) - z[1] - acor,  y = z[0] + l0 acor
-            bool converged = false, fresh = false;
-            int n_iter = 0;
-            while (!converged) {
+        for (int v = 0; v < V; ++v)
+            isc[v] = __builtin_amdgcn_rcpf(fmaf(is_E(v) ? rtol_E_f : rtol_f, fabsf((float)z[0][v]), is_E(v) ? atol_E_f : atol_f));
+        // per-node step: zero on the padded slots (node >= L), whose right-hand side is never looked at
+        real hv[R];
 #pragma unroll
-                for (int v = 0; v < V; ++v) { acor[v] = (real)0; yn[v] = z[0][v]; }
+        for (int r = 0; r < R; ++r) hv[r] = (bk.node(r) < L) ? h : (real)0;
+        MTRPL_STAMP(ph_ctl);
+
+        // ---- simplified Newton on acor:  (I - h l0 J) dx = h f(y) - z[1] - acor,  y = z[0] + l0 acor ----
+        real acor[V], yn[V];
+        float acf[V];  // acor as fp32: what the norms see, and the next step's `acp`
+        ctl dsm = 0.0f, ssel0 = 0.0f, ssel1 = 0.0f;
+        int converged = 0, n_iter = 0, fresh = 0;
+        for (;;) {  // with the kept factors, then once more with fresh ones
 #pragma unroll
-                for (int r = 0; r < R; ++r) zE[r] = z[1][2 * R + r];
+            for (int v = 0; v < V; ++v) { acor[v] = (real)0; yn[v] = z[0][v]; }
+            if (!have_fac) {
+                // the analytic Jacobian is evaluated inside the factorisation: always at the predictor
                 MTRPL_STAMP(ph_glue);
-                bk.publish(yn, zE);
-                MTRPL_STAMP(ph_red);
-                if (!have_fac) {
-                    // the analytic Jacobian is evaluated inside the factorisation: always at the predictor
-                    bk.build(z[0], c, h);
-                    MTRPL_STAMP(ph_fac);
-                    have_fac = true;
-                    fresh = true;
-                    n_fac++;
-                    n_jac++;
-                    rate_prev = (real)1;  // new matrix: measure the rate afresh
-                    rate_age = 0;
-                }
-                real dn_old = (real)0;
-                for (int k = 0; k < 4; ++k) {
-                    n_iter = k + 1;
-                    MTRPL_STAMP(ph_glue);
-                    bk.rhs(yn, f);
-                    MTRPL_STAMP(ph_rhs);
-                    n_rhs++;
-                    real b[V], dxv[V];
+                bk.build(z[0], c);
+                MTRPL_STAMP(ph_fac);
+                have_fac = 1;
+                fresh = 1;
+                n_fac++;
+                rate_prev = 1.0f;  // new matrix: measure the rate afresh
+                rate_age = 0;
+            }
+            ctl dn_old = 0.0f;
+            for (int k = 0; k < 4; ++k) {
+                n_iter = k + 1;
+                MTRPL_STAMP(ph_glue);
+                bk.rhs(yn, f);
+                MTRPL_STAMP(ph_rhs);
+                n_rhs++;
+                real b[V], dxv[V];
 #pragma unroll
-                    for (int v = 0; v < V; ++v) b[v] = h * f[v] - z[1][v] - acor[v];
-                    MTRPL_STAMP(ph_glue);
-                    bk.apply(b, dxv);
-                    MTRPL_STAMP(ph_app);
-                    // the update is applied before the convergence decision (a rejected iterate is simply
-                    // discarded): the norms of the increment and of the whole correction, and the boundary
-                    // state the next rhs() needs, then share one reduction
-                    real s4[4] = {(real)0, (real)0, (real)0, (real)0};
+                for (int v = 0; v < V; ++v) b[v] = hv[v % R] * f[v] - z[1][v] - acor[v];
+                MTRPL_STAMP(ph_glue);
+                bk.apply(b, dxv);
+                MTRPL_STAMP(ph_app);
+                // the update is applied before the convergence decision (a rejected iterate is simply
+                // discarded): the norms of the increment and of the whole correction then share one reduction
+                float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    acor[v] += dxv[v];
+                    yn[v] += el0 * dxv[v];
+                    const float wv = (float)dxv[v] * isc[v];
+                    acf[v] = (float)acor[v];
+                    const float av = acf[v] * isc[v];
+                    s4[0] = fmaf(wv, wv, s4[0]);
+                    s4[1] = fmaf(av, av, s4[1]);
+                }
+                if (will_select) {
+                    // stode: ddn from the last Nordsieck row (after the correction), dup from acor - acor_prev
+                    const float elK = (float)nq.elK;
+                    // (a switch with one loop per case: a select chain over z[1..5][v] is turned into a load with a
+                    // run-time row index, and the whole history then lives in memory)
+#define MTRPL_DDN_ROW(J) for (int v = 0; v < V; ++v) { const float q_ = fmaf(elK, acf[v], (float)z[J][v]) * isc[v]; s4[2] = fmaf(q_, q_, s4[2]); }
+                    switch (order) {
+                        case 1: MTRPL_DDN_ROW(1) break;
+                        case 2: MTRPL_DDN_ROW(2) break;
+                        case 3: MTRPL_DDN_ROW(3) break;
+                        case 4: MTRPL_DDN_ROW(4) break;
+                        default: MTRPL_DDN_ROW(5) break;
+                    }
+#undef MTRPL_DDN_ROW
 #pragma unroll
                     for (int v = 0; v < V; ++v) {
-                        const real wv = el0 * dxv[v] * isc[v];
-                        s4[0] += wv * wv;
-                        acor[v] += dxv[v];
-                        yn[v] += el0 * dxv[v];
-                        const real av = acor[v] * isc[v];
-                        s4[1] += av * av;
+                        const float a_ = (acf[v] - acp[v]) * isc[v];
+                        s4[3] = fmaf(a_, a_, s4[3]);
                     }
-#pragma unroll
-                    for (int r = 0; r < R; ++r) zE[r] = z[1][2 * R + r] + acor[2 * R + r];
-                    if (will_select) {
-                        // stode: ddn from the last Nordsieck row (after the correction), dup from acor - acor_prev
-                        switch (order) {
-                            case 1: for (int v = 0; v < V; ++v) { const real q_ = (z[1][v] + elK * acor[v]) * isc[v]; s4[2] += q_ * q_; } break;
-                            case 2: for (int v = 0; v < V; ++v) { const real q_ = (z[2][v] + elK * acor[v]) * isc[v]; s4[2] += q_ * q_; } break;
-                            case 3: for (int v = 0; v < V; ++v) { const real q_ = (z[3][v] + elK * acor[v]) * isc[v]; s4[2] += q_ * q_; } break;
-                            case 4: for (int v = 0; v < V; ++v) { const real q_ = (z[4][v] + elK * acor[v]) * isc[v]; s4[2] += q_ * q_; } break;
-                            default: for (int v = 0; v < V; ++v) { const real q_ = (z[5][v] + elK * acor[v]) * isc[v]; s4[2] += q_ * q_; } break;
-                        }
-#pragma unroll
-                        for (int v = 0; v < V; ++v) {
-                            const real a_ = (acor[v] - acp[v]) * isc[v];
-                            s4[3] += a_ * a_;
-                        }
-                        MTRPL_STAMP(ph_glue);
-                        bk.template reduce<4>(s4, yn, zE);
-                    } else {
-                        real s2[2] = {s4[0], s4[1]};
-                        MTRPL_STAMP(ph_glue);
-                        bk.template reduce<2>(s2, yn, zE);
-                        s4[0] = s2[0];
-                        s4[1] = s2[1];
-                    }
-                    MTRPL_STAMP(ph_red);
-                    const real dn = norm_sqrt(s4[0] * inv_S);
-                    if (!(dn < big<real>())) break;  // NaN / inf
-                    real rate = rate_prev;
-                    const bool negligible = dn < (real)1e-2 * newton_tol;
-                    if (k > 0) {
-                        rate = dn * ctl_rcp(dn_old);
-                        if (!negligible) {
-                            real rp = rate;  // rate^(4-k)
-                            for (int q = 1; q < 4 - k; ++q) rp *= rate;
-                            if (rate >= (real)1 || rp * dn > newton_tol * ((real)1 - rate)) break;
-                        }
-                        if (rate < (real)1) {
-                            rate_prev = (rate_prev >= (real)1 && tune.rate_first_safety > 0.0)
-                                            ? fmin(fmax((real)tune.rate_first_safety * rate, (real)1e-4), (real)0.9)
-                                            : fmax((real)0.3 * rate_prev, rate);
-                            rate_age = 0;
-                        }
-                    }
-                    const bool rate_ok = (k > 0) || (rate_prev < (real)0.9 && rate_age < tune.rate_max_age);
-                    if (negligible || (rate_ok && rate < (real)1 && rate * dn < newton_tol * ((real)1 - rate))) {
-                        converged = true;
-                        dsm = norm_sqrt(s4[1] * inv_S) * inv_t2;
-                        ssel0 = s4[2];
-                        ssel1 = s4[3];
-                        break;
-                    }
-                    dn_old = dn;
+                    MTRPL_STAMP(ph_glue);
+                    bk.template reduce_f<4>(s4);
+                } else {
+                    float s2[2] = {s4[0], s4[1]};
+                    MTRPL_STAMP(ph_glue);
+                    bk.template reduce_f<2>(s2);
+                    s4[0] = s2[0];
+                    s4[1] = s2[1];
                 }
-                if (converged && n_iter == 1) rate_age++;
-                if (!converged) {
-                    if (fresh) break;
-                    have_fac = false;  // refactor with the Jacobian at this predictor, then try once more
+                MTRPL_STAMP(ph_red);
+                // norm of the increment of y = l0 * dx
+                const ctl dn = (ctl)el0 * nscale * __builtin_amdgcn_sqrtf(s4[0] * inv_S);
+                if (!(dn < 1e30f)) break;  // NaN / inf
+                ctl rate = rate_prev;
+                const bool negligible = dn < 1e-2f * newton_tol;
+                if (k > 0) {
+                    rate = dn * __builtin_amdgcn_rcpf(dn_old);
+                    if (!negligible) {
+                        ctl rp = rate;  // rate^(4-k)
+                        for (int q = 1; q < 4 - k; ++q) rp *= rate;
+                        if (rate >= 1.0f || rp * dn > newton_tol * (1.0f - rate)) break;
+                    }
+                    if (rate < 1.0f) {
+                        rate_prev = (rate_prev >= 1.0f && tune.rate_first_safety > 0.0)
+                                        ? fminf(fmaxf((ctl)tune.rate_first_safety * rate, 1e-4f), 0.9f)
+                                        : fmaxf(0.3f * rate_prev, rate);
+                        rate_age = 0;
+                    }
                 }
+                const bool rate_ok = (k > 0) || (rate_prev < 0.9f && rate_age < tune.rate_max_age);
+                if (negligible || (rate_ok && rate < 1.0f && rate * dn < newton_tol * (1.0f - rate))) {
+                    converged = 1;
+                    dsm = nscale * __builtin_amdgcn_sqrtf(s4[1] * inv_S) * (ctl)nq.inv_t2;
+                    ssel0 = s4[2];
+                    ssel1 = s4[3];
+                    break;
+                }
+                dn_old = dn;
             }
-            if (!converged) {
-                n_nfail++;
-                nq_retract<5, V>(z);
-                nq_rescale<5, V>(z, (real)0.5);
-                h *= (real)0.5;
-                n_equal = 0;
-                have_fac = false;
-                continue;
-            }
-            MTRPL_STAMP(ph_glue);
-            // 0.9 * (2*4 + 1) / (2*4 + n_iter), n_iter = 1..4
-            safety = (n_iter == 1) ? (real)0.9 : ((n_iter == 2) ? (real)0.81 : ((n_iter == 3) ? (real)(8.1 / 11.0) : (real)0.675));
-            if (dsm > (real)1) {
-                n_rej++;
-                since_rej = 0;
-                const real fac = fmax((real)0.2, safety * inv_root(dsm, order + 1));
-                nq_retract<5, V>(z);
-                nq_rescale<5, V>(z, fac);
-                h *= fac;
-                n_equal = 0;
-                have_fac = false;
-            } else {
-                accepted = true;
-            }
+            if (converged || fresh) break;
+            have_fac = 0;  // refactor with the Jacobian at this predictor, then try once more
         }
-        if (!accepted) break;
-        MTRPL_STAMP(ph_ctl);
-        const bool selecting = n_equal >= order;  // = will_select of the accepted attempt
+        if (converged && n_iter == 1) rate_age++;
+        MTRPL_STAMP(ph_glue);
+        if (!converged) {
+            TRACE(2, n_iter, dsm);
+            n_bad += 1 << 16;
+            fails++;
+            nq_retract<5, V>(z);
+            nq_rescale<5, V>(z, (real)0.5);
+            h *= (real)0.5;
+            n_equal = 0;
+            have_fac = 0;
+            continue;
+        }
+        // 0.9 * (2*4 + 1) / (2*4 + n_iter), n_iter = 1..4
+        const ctl safety = (n_iter == 1) ? 0.9f : ((n_iter == 2) ? 0.81f : ((n_iter == 3) ? (ctl)(8.1 / 11.0) : 0.675f));
+        if (dsm > 1.0f) {
+            TRACE(1, n_iter, dsm);
+            n_bad++;
+            fails++;
+            since_rej = 0;
+            const real fac = (real)fmaxf(0.2f, safety * pow_ctl(dsm, -nq.inv_qp1));
+            nq_retract<5, V>(z);
+            nq_rescale<5, V>(z, fac);
+            h *= fac;
+            n_equal = 0;
+            have_fac = 0;
+            continue;
+        }
+        // ---- accepted ----
+        TRACE(0, n_iter, dsm);
+        fails = 0;
+        const bool selecting = will_select;
         n_steps++;
         n_equal++;
         since_rej++;
         t += h;
-        {
-            real el[6];
-            MTRPL_ORDER_SWITCH(order, (el[0] = (real)NqC<K>::T.el[K][0], el[1] = (real)NqC<K>::T.el[K][1], el[2] = (real)NqC<K>::T.el[K][2],
-                                       el[3] = (real)NqC<K>::T.el[K][3], el[4] = (real)NqC<K>::T.el[K][4], el[5] = (real)NqC<K>::T.el[K][5]))
-            nq_correct_rt<V>(z, acor, el);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const real elj = (real)nq.el[j];  // zero above the order: those rows stay zero
+#pragma unroll
+            for (int v = 0; v < V; ++v) z[j][v] += elj * acor[v];
         }
+#pragma unroll
+        for (int v = 0; v < V; ++v) acp[v] = acf[v];
         MTRPL_STAMP(ph_ctl);
-        // dense output (Taylor polynomial of the Nordsieck array), forward_solver.py:167
-        const real ih = frcp(h);
-        while (io < nt) {
-            const real tq = tq_next;  // = ts[io], loaded one output ahead
-            if (tq > t * (real)(1.0 + 1e-15)) break;
-            real yq[V];
-            const real s_ = (tq - t) * ih;
-            nq_dense<5, V>(z, s_, yq);
-            bk.out_sample(io, sig_partial(yq));
-            io++;
-            tq_next = (io < nt) ? (real)ts[io] : big<real>();
+        // dense output (Taylor polynomial of the Nordsieck array), forward_solver.py:167: only N and P enter the signal
+        if (!(tq_next > t * (real)(1.0 + 1e-15))) {
+            const real ih = frcp(h);
+            do {
+                const real s_ = (tq_next - t) * ih;
+                real nn[R], pp[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    nn[r] = z[5][r];
+                    pp[r] = z[5][R + r];
+                }
+#pragma unroll
+                for (int j = 4; j >= 0; --j)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        nn[r] = nn[r] * s_ + z[j][r];
+                        pp[r] = pp[r] * s_ + z[j][R + r];
+                    }
+                bk.out_sample(io, sig_partial(nn, pp));
+                io++;
+                if (io - io0 >= 64) {
+                    io0 = io;
+                    tsv = (io0 + lane64 < nt) ? ts[io0 + lane64] : 1e300;
+                }
+                tq_next = (io < nt) ? (real)lane_value(tsv, io - io0) : big<real>();
+            } while (!(tq_next > t * (real)(1.0 + 1e-15)));
         }
         MTRPL_STAMP(ph_dense);
-#pragma unroll
-        for (int v = 0; v < V; ++v) acp[v] = acor[v];
         if (!selecting) continue;
-        // order / step-size selection (stode)
-        real inv_t1 = (real)1, inv_t3 = (real)1, el_up = (real)0;
-        float e0 = -0.5f, e1 = -0.5f, e2 = -0.5f;
-        MTRPL_ORDER_SWITCH(order, (inv_t1 = (real)NqC<K>::inv_t1, inv_t3 = (real)NqC<K>::inv_t3, el_up = (real)NqC<K>::el_up,
-                                   e0 = NqC<K>::nik0, e1 = NqC<K>::nik1, e2 = NqC<K>::nik2))
-        const real ddn = (order > 1) ? inv_t1 * norm_sqrt(ssel0 * inv_S) : big<real>();
-        const real dup = (order < 5) ? inv_t3 * norm_sqrt(ssel1 * inv_S) : big<real>();
-        const real fm = (order > 1) ? pow_neg_inv(ddn, e0) : (real)0;
-        const real f0 = pow_neg_inv(dsm, e1);
-        const real fp = (order < 5) ? pow_neg_inv(dup, e2) : (real)0;
+        // ---- order / step-size selection (stode) ----
+        // The three candidate factors are x^e with their own x and e: evaluated as ONE log2 / multiply / exp2
+        // sequence on lanes 0..2 (nothing here is lane-uniform until the three results are read back).
+        ctl fm, f0, fp;
+        {
+            const ctl ddn = nscale * (ctl)nq.inv_t1 * __builtin_amdgcn_sqrtf(ssel0 * inv_S);
+            const ctl dup = nscale * (ctl)nq.inv_t3 * __builtin_amdgcn_sqrtf(ssel1 * inv_S);
+            ctl x = (lane64 == 0) ? ddn : ((lane64 == 1) ? dsm : dup);
+            const ctl e = (lane64 == 0) ? nq.nik0 : ((lane64 == 1) ? nq.nik1 : nq.nik2);
+            x = fminf(fmaxf(x, 1e-30f), 1e30f);
+            const ctl pw = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * e);
+            fm = (order > 1) ? lane_value(pw, 0) : 0.0f;
+            f0 = lane_value(pw, 1);
+            fp = (order < 5) ? lane_value(pw, 2) : 0.0f;
+        }
         // stode's biases: a change of order has to promise more than staying (1.2 / 1.3 / 1.4)
         int dorder = 0;
-        real fbest = f0 * (real)tune.nq_bias_same;
-        if (fm * (real)tune.nq_bias_down > fbest) { fbest = fm * (real)tune.nq_bias_down; dorder = -1; }
-        if (fp * (real)tune.nq_bias_up > fbest) { fbest = fp * (real)tune.nq_bias_up; dorder = 1; }
-        real fac = fmin((real)10, (tune.nq_bias_same < 1.0 ? (real)1 : safety) * fbest);
+        ctl fbest = f0 * (ctl)tune.nq_bias_same;
+        if (fm * (ctl)tune.nq_bias_down > fbest) { fbest = fm * (ctl)tune.nq_bias_down; dorder = -1; }
+        if (fp * (ctl)tune.nq_bias_up > fbest) { fbest = fp * (ctl)tune.nq_bias_up; dorder = 1; }
+        ctl facf = fminf(10.0f, (tune.nq_bias_same < 1.0 ? 1.0f : safety) * fbest);
         // a step that was rejected a moment ago says the estimates behind `fac` are optimistic here (stiff
         // surface terms): grow cautiously for a while instead of hunting (reject / shrink / regrow / reject)
-        if (since_rej < tune.nq_rej_memory) fac = fmin(fac, (real)tune.nq_rej_growth);
+        if (since_rej < tune.nq_rej_memory) facf = fminf(facf, (ctl)tune.nq_rej_growth);
+        real fac = (real)facf;
         // max_step guards LSODA against stepping over structure; once the signal is down in the rounding noise
         // of N P - n0 p0 (hmax_deep, 11 decades by default) there is none left and the error test alone decides
-        if (h * fac > hmax && !bk.deep()) fac = hmax * ih;
+        if (h * fac > hmax && !bk.deep()) fac = hmax * frcp(h);
         if (dorder == 0 && fac >= (real)0.9 && fac < (real)tune.nq_deadband_hi) {
             n_equal = order - 2;  // keep h and the factors; test again three steps on
             continue;
@@ -638,6 +674,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             // order up: the new last row is z[q+1] = acor * l_q / (q+1); order down: the last row is dropped,
             // i.e. zeroed.  Row j = 2..5 is scaled by keep_j and receives add_j * acor (both wave-uniform).
             const int qn = order + dorder;
+            const real el_up = (real)nq.el_up;
 #pragma unroll
             for (int j = 2; j < 6; ++j) {
                 const real keep = (j <= qn && j <= order) ? (real)1 : (real)0;
@@ -650,26 +687,25 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         nq_rescale<5, V>(z, fac);
         h *= fac;
         n_equal = 0;
-        have_fac = false;
+        have_fac = 0;
     }
 
     if (st != MTRPL_SOLVE_OK) {
         // forward_solver.py:168: samples after the last solved time come from a zeroed state
-        real zero_[V];
+        real zn[R], zp[R];
 #pragma unroll
-        for (int v = 0; v < V; ++v) zero_[v] = (real)0;
-        const real zp = sig_partial(zero_);
-        for (; io < nt; ++io) bk.out_sample(io, zp);
+        for (int r = 0; r < R; ++r) { zn[r] = (real)0; zp[r] = (real)0; }
+        const real zsig = sig_partial(zn, zp);
+        for (; io < nt; ++io) bk.out_sample(io, zsig);
     } else if (tol_clamped) {
         st = MTRPL_SOLVE_OK_TOL_CLAMPED;
     }
-    bk.out_finish();
     if (bk.leader()) {
         status[sidx] = st;
         if (stats) {
             int32_t *s = stats + 8 * sidx;
-            s[0] = n_steps; s[1] = n_rhs; s[2] = n_fac; s[3] = n_jac;
-            s[4] = n_rej; s[5] = n_nfail; s[6] = order;
+            s[0] = n_steps; s[1] = n_rhs; s[2] = n_fac; s[3] = n_fac + 1;  // a Jacobian per factorisation + the initial one
+            s[4] = n_bad & 0xffff; s[5] = n_bad >> 16; s[6] = order;
             s[7] = (int32_t)((__builtin_amdgcn_s_memtime() - clk0_) >> 4);  // residency of this solve, 16-tick units
 #ifdef MTRPL_SCHED  // diagnostic build (tools/sched_trace.py): when (100 MHz real-time counter) and where the solve ran
             s[5] = (int32_t)(sched_t0_ & 0x7fffffff);

@@ -321,3 +321,24 @@ def test_census_subset_within_gate(variant):
     print(f"census subset: max {errs.max():.2e} p90 {np.percentile(errs, 90):.2e} median {np.median(errs):.2e}")
     assert errs.max() <= 1e-6, (int(errs.argmax()), errs.max())
     assert np.median(errs) <= 1e-7
+
+
+def test_controller_wave_reductions():
+    """device_math.hpp wave_sums_f<1|2|4>: the merged fp32 DPP / permlane-swap ladders the error norms go through,
+    on data whose rows of 16 lanes differ wildly (a norm concentrated in one quarter of the grid must not be lost)."""
+    import ctypes as C
+    from metrotrpl_amd import _lib as L
+    ctx = L.default_context()
+    rng = np.random.default_rng(5)
+    B = 64
+    x = rng.uniform(0, 1, (B, 4, 64)).astype(np.float32)
+    x[1, :, :48] = 0                      # everything in the last row of 16 lanes
+    x[2, :, 16:] = 0                      # ... in the first
+    x[3] = 0
+    x[3, :, 37] = [1, 2, 3, 4]            # one lane
+    x[4] *= (10.0 ** rng.uniform(-20, 20, (4, 64))).astype(np.float32)
+    out = np.zeros((B, 7), dtype=np.float32)
+    ctx.check(L.lib().mtrpl_reduce_probe(ctx.handle, B, x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+    ref = x.astype(np.float64).sum(axis=2)
+    want = np.stack([ref[:, 0], ref[:, 0], ref[:, 1], ref[:, 0], ref[:, 1], ref[:, 2], ref[:, 3]], axis=1)
+    np.testing.assert_allclose(out, want, rtol=2e-6)
