@@ -278,7 +278,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             excl += own[r];
         }
     }
-    dNmax = bk.max_all(dNmax);
+    dNmax = uniform(bk.max_all(dNmax));
 
     // ---- tolerances (DESIGN.md "error control") ----
     // The contract is the converged solution, so a loose RTOL does not loosen the integration
@@ -365,7 +365,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             real m = (real)0;
 #pragma unroll
             for (int k = 0; k < V; ++k) m = fmax(m, fabs(vv[k]));
-            m = bk.max_all(m);
+            m = uniform(bk.max_all(m));  // (readfirstlane: the compiler must know that the step size is wave-uniform)
             if (!(m > (real)0) || !(m < big<real>())) return m;
             const real im = (real)1 / m;
             float s1[1] = {0.0f};
@@ -566,128 +566,128 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         }
         if (converged && n_iter == 1) rate_age++;
         MTRPL_STAMP(ph_glue);
-        if (!converged) {
-            TRACE(2, n_iter, dsm);
-            n_bad += 1 << 16;
-            fails++;
-            nq_retract<5, V>(z);
-            nq_rescale<5, V>(z, (real)0.5);
-            h *= (real)0.5;
-            n_equal = 0;
-            have_fac = 0;
-            continue;
-        }
         // 0.9 * (2*4 + 1) / (2*4 + n_iter), n_iter = 1..4
         const ctl safety = (n_iter == 1) ? 0.9f : ((n_iter == 2) ? 0.81f : ((n_iter == 3) ? (ctl)(8.1 / 11.0) : 0.675f));
-        if (dsm > 1.0f) {
-            TRACE(1, n_iter, dsm);
-            n_bad++;
+        // What the step does to the history afterwards: nothing, or z[j] <- kf[j] z[j] + af[j] acor (a change of step
+        // size and/or order), preceded by a retraction of the prediction when the attempt is thrown away.  ONE place
+        // writes the history back and the loop has one back edge: the register allocation of the 72-register history
+        // does not have to be reconciled between five ways round the loop.
+        bool rework = false;
+        real facz = (real)1;
+        int qn = order;
+        if (!converged || dsm > 1.0f) {
+            // Newton failed with fresh factors (halve the step) or the error test failed (stode's factor)
+            TRACE(converged ? 1 : 2, n_iter, dsm);
+            n_bad += converged ? 1 : (1 << 16);
             fails++;
-            since_rej = 0;
-            const real fac = (real)fmaxf(0.2f, safety * pow_ctl(dsm, -nq.inv_qp1));
+            if (converged) since_rej = 0;
+            facz = converged ? (real)fmaxf(0.2f, safety * pow_ctl(dsm, -nq.inv_qp1)) : (real)0.5;
             nq_retract<5, V>(z);
-            nq_rescale<5, V>(z, fac);
-            h *= fac;
-            n_equal = 0;
-            have_fac = 0;
-            continue;
-        }
-        // ---- accepted ----
-        TRACE(0, n_iter, dsm);
-        fails = 0;
-        const bool selecting = will_select;
-        n_steps++;
-        n_equal++;
-        since_rej++;
-        t += h;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const real elj = (real)nq.el[j];  // zero above the order: those rows stay zero
+            for (int v = 0; v < V; ++v) acor[v] = (real)0;
+            rework = true;
+        } else {
+            // ---- accepted ----
+            TRACE(0, n_iter, dsm);
+            fails = 0;
+            n_steps++;
+            n_equal++;
+            since_rej++;
+            t += h;
 #pragma unroll
-            for (int v = 0; v < V; ++v) z[j][v] += elj * acor[v];
-        }
+            for (int j = 0; j < 6; ++j) {
+                const real elj = (real)nq.el[j];  // zero above the order: those rows stay zero
 #pragma unroll
-        for (int v = 0; v < V; ++v) acp[v] = acf[v];
-        MTRPL_STAMP(ph_ctl);
-        // dense output (Taylor polynomial of the Nordsieck array), forward_solver.py:167: only N and P enter the signal
-        if (!(tq_next > t * (real)(1.0 + 1e-15))) {
-            const real ih = frcp(h);
-            do {
-                const real s_ = (tq_next - t) * ih;
-                real nn[R], pp[R];
+                for (int v = 0; v < V; ++v) z[j][v] += elj * acor[v];
+            }
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    nn[r] = z[5][r];
-                    pp[r] = z[5][R + r];
-                }
-#pragma unroll
-                for (int j = 4; j >= 0; --j)
+            for (int v = 0; v < V; ++v) acp[v] = acf[v];
+            MTRPL_STAMP(ph_ctl);
+            // dense output (Taylor polynomial of the Nordsieck array), forward_solver.py:167: only N and P enter the signal
+            if (!(tq_next > t * (real)(1.0 + 1e-15))) {
+                const real ih = frcp(h);
+                do {
+                    const real s_ = (tq_next - t) * ih;
+                    real nn[R], pp[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        nn[r] = nn[r] * s_ + z[j][r];
-                        pp[r] = pp[r] * s_ + z[j][R + r];
+                        nn[r] = z[5][r];
+                        pp[r] = z[5][R + r];
                     }
-                bk.out_sample(io, sig_partial(nn, pp));
-                io++;
-                if (io - io0 >= 64) {
-                    io0 = io;
-                    tsv = (io0 + lane64 < nt) ? ts[io0 + lane64] : 1e300;
+#pragma unroll
+                    for (int j = 4; j >= 0; --j)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            nn[r] = nn[r] * s_ + z[j][r];
+                            pp[r] = pp[r] * s_ + z[j][R + r];
+                        }
+                    bk.out_sample(io, sig_partial(nn, pp));
+                    io++;
+                    if (io - io0 >= 64) {
+                        io0 = io;
+                        tsv = (io0 + lane64 < nt) ? ts[io0 + lane64] : 1e300;
+                    }
+                    tq_next = (io < nt) ? (real)lane_value(tsv, io - io0) : big<real>();
+                } while (!(tq_next > t * (real)(1.0 + 1e-15)));
+            }
+            MTRPL_STAMP(ph_dense);
+            if (will_select) {
+                // ---- order / step-size selection (stode) ----
+                // The three candidate factors are x^e with their own x and e: evaluated as ONE log2 / multiply / exp2
+                // sequence on lanes 0..2 (nothing here is lane-uniform until the three results are read back).
+                ctl fm, f0, fp;
+                {
+                    const ctl ddn = nscale * (ctl)nq.inv_t1 * __builtin_amdgcn_sqrtf(ssel0 * inv_S);
+                    const ctl dup = nscale * (ctl)nq.inv_t3 * __builtin_amdgcn_sqrtf(ssel1 * inv_S);
+                    ctl x = (lane64 == 0) ? ddn : ((lane64 == 1) ? dsm : dup);
+                    const ctl e = (lane64 == 0) ? nq.nik0 : ((lane64 == 1) ? nq.nik1 : nq.nik2);
+                    x = fminf(fmaxf(x, 1e-30f), 1e30f);
+                    const ctl pw = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * e);
+                    fm = (order > 1) ? lane_value(pw, 0) : 0.0f;
+                    f0 = lane_value(pw, 1);
+                    fp = (order < 5) ? lane_value(pw, 2) : 0.0f;
                 }
-                tq_next = (io < nt) ? (real)lane_value(tsv, io - io0) : big<real>();
-            } while (!(tq_next > t * (real)(1.0 + 1e-15)));
+                // stode's biases: a change of order has to promise more than staying (1.2 / 1.3 / 1.4)
+                int dorder = 0;
+                ctl fbest = f0 * (ctl)tune.nq_bias_same;
+                if (fm * (ctl)tune.nq_bias_down > fbest) { fbest = fm * (ctl)tune.nq_bias_down; dorder = -1; }
+                if (fp * (ctl)tune.nq_bias_up > fbest) { fbest = fp * (ctl)tune.nq_bias_up; dorder = 1; }
+                ctl facf = fminf(10.0f, (tune.nq_bias_same < 1.0 ? 1.0f : safety) * fbest);
+                // a step that was rejected a moment ago says the estimates behind `fac` are optimistic here (stiff
+                // surface terms): grow cautiously for a while instead of hunting (reject / shrink / regrow / reject)
+                if (since_rej < tune.nq_rej_memory) facf = fminf(facf, (ctl)tune.nq_rej_growth);
+                real fac = (real)facf;
+                // max_step guards LSODA against stepping over structure; once the signal is down in the rounding noise
+                // of N P - n0 p0 (hmax_deep, 11 decades by default) there is none left and the error test alone decides
+                if (h * fac > hmax && !bk.deep()) fac = hmax * frcp(h);
+                if (dorder == 0 && fac >= (real)0.9 && fac < (real)tune.nq_deadband_hi) {
+                    n_equal = order - 2;  // keep h and the factors; test again three steps on
+                } else {
+                    facz = fac;
+                    qn = order + dorder;
+                    rework = true;
+                }
+            }
         }
-        MTRPL_STAMP(ph_dense);
-        if (!selecting) continue;
-        // ---- order / step-size selection (stode) ----
-        // The three candidate factors are x^e with their own x and e: evaluated as ONE log2 / multiply / exp2
-        // sequence on lanes 0..2 (nothing here is lane-uniform until the three results are read back).
-        ctl fm, f0, fp;
-        {
-            const ctl ddn = nscale * (ctl)nq.inv_t1 * __builtin_amdgcn_sqrtf(ssel0 * inv_S);
-            const ctl dup = nscale * (ctl)nq.inv_t3 * __builtin_amdgcn_sqrtf(ssel1 * inv_S);
-            ctl x = (lane64 == 0) ? ddn : ((lane64 == 1) ? dsm : dup);
-            const ctl e = (lane64 == 0) ? nq.nik0 : ((lane64 == 1) ? nq.nik1 : nq.nik2);
-            x = fminf(fmaxf(x, 1e-30f), 1e30f);
-            const ctl pw = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * e);
-            fm = (order > 1) ? lane_value(pw, 0) : 0.0f;
-            f0 = lane_value(pw, 1);
-            fp = (order < 5) ? lane_value(pw, 2) : 0.0f;
-        }
-        // stode's biases: a change of order has to promise more than staying (1.2 / 1.3 / 1.4)
-        int dorder = 0;
-        ctl fbest = f0 * (ctl)tune.nq_bias_same;
-        if (fm * (ctl)tune.nq_bias_down > fbest) { fbest = fm * (ctl)tune.nq_bias_down; dorder = -1; }
-        if (fp * (ctl)tune.nq_bias_up > fbest) { fbest = fp * (ctl)tune.nq_bias_up; dorder = 1; }
-        ctl facf = fminf(10.0f, (tune.nq_bias_same < 1.0 ? 1.0f : safety) * fbest);
-        // a step that was rejected a moment ago says the estimates behind `fac` are optimistic here (stiff
-        // surface terms): grow cautiously for a while instead of hunting (reject / shrink / regrow / reject)
-        if (since_rej < tune.nq_rej_memory) facf = fminf(facf, (ctl)tune.nq_rej_growth);
-        real fac = (real)facf;
-        // max_step guards LSODA against stepping over structure; once the signal is down in the rounding noise
-        // of N P - n0 p0 (hmax_deep, 11 decades by default) there is none left and the error test alone decides
-        if (h * fac > hmax && !bk.deep()) fac = hmax * frcp(h);
-        if (dorder == 0 && fac >= (real)0.9 && fac < (real)tune.nq_deadband_hi) {
-            n_equal = order - 2;  // keep h and the factors; test again three steps on
-            continue;
-        }
-        if (dorder != 0) {
-            // order up: the new last row is z[q+1] = acor * l_q / (q+1); order down: the last row is dropped,
-            // i.e. zeroed.  Row j = 2..5 is scaled by keep_j and receives add_j * acor (both wave-uniform).
-            const int qn = order + dorder;
+        if (rework) {
+            // Row j = 1..5 is scaled by fac^j; on an order increase the new last row is acor * l_q / (q+1) (times
+            // fac^(q+1)), on an order decrease the dropped row is zeroed: z[j] <- kf[j] z[j] + af[j] acor, wave-uniform
+            // kf, af (acor is zero after a discarded attempt).
             const real el_up = (real)nq.el_up;
+            real r = (real)1;
 #pragma unroll
-            for (int j = 2; j < 6; ++j) {
-                const real keep = (j <= qn && j <= order) ? (real)1 : (real)0;
-                const real add = (dorder == 1 && j == qn) ? el_up : (real)0;
+            for (int j = 1; j < 6; ++j) {
+                r *= facz;
+                const real kf = (j <= qn && j <= order) ? r : (real)0;
+                const real af = (qn > order && j == qn) ? el_up * r : (real)0;
 #pragma unroll
-                for (int v = 0; v < V; ++v) z[j][v] = keep * z[j][v] + add * acor[v];
+                for (int v = 0; v < V; ++v) z[j][v] = kf * z[j][v] + af * acor[v];
             }
             order = qn;
+            h *= facz;
+            n_equal = 0;
+            have_fac = 0;
         }
-        nq_rescale<5, V>(z, fac);
-        h *= fac;
-        n_equal = 0;
-        have_fac = 0;
     }
 
     if (st != MTRPL_SOLVE_OK) {
