@@ -219,7 +219,7 @@ struct TeamBackend {
             const real NP = N * P - p.n0p0;
             real jnr = Jn[r + 1], jpr = Jp[r + 1];
             if (i == L - 1) {  // :347,:350,:352
-                const real Sbt = p.Sb * NP * frcp(N + P);
+                const real Sbt = p.Sb * NP * frcp1(N + P);
                 jnr = -Sbt;
                 jpr = Sbt;
             }

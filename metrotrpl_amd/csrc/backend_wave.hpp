@@ -128,7 +128,7 @@ struct WaveBackendT {
             const double NP = N * P - p.n0p0;
             double jnr = Jn[r + 1], jpr = Jp[r + 1];
             if (i == L - 1) {  // :347,:350,:352
-                const double Sbt = p.Sb * NP * frcp(N + P);
+                const double Sbt = p.Sb * NP * frcp1(N + P);
                 jnr = -Sbt;
                 jpr = Sbt;
             }
@@ -262,7 +262,8 @@ struct WaveBackendT {
         const v2f r0 = narrow(r[0]);
         const v2f r0_up{from_next(r0.x), from_next(r0.y)};
         const v2f t = pb_acc(cr_ga, r0_up, pb_acc(cr_al, r0, v2f(0.0f)));
-        V2 rk{r[1].x - (double)t.x, r[1].y - (double)t.y};
+        // the reduced right-hand side goes through the six PCR levels as fp32: every product it meets is fp32 already
+        v2f rk32 = narrow(V2{r[1].x - (double)t.x, r[1].y - (double)t.y});
         PB b_inv = al, b_ia = al, b_ic = al;
 #pragma unroll
         for (int lv = 0; lv < 6; ++lv) {
@@ -276,7 +277,7 @@ struct WaveBackendT {
                 b_ia = get_pb(BIA_E);
                 b_ic = get_pb(BIC_E);
             }
-            const v2f rf = narrow(rk);
+            const v2f rf = rk32;
             v2f rm, rp;
             if (lv == 0) {
                 rm = v2f{from_prev(rf.x), from_prev(rf.y)};
@@ -291,11 +292,11 @@ struct WaveBackendT {
                 rm = v2f{shf(rf.x, (lane - s) & 63), shf(rf.y, (lane - s) & 63)};
                 rp = v2f{shf(rf.x, (lane + s) & 63), shf(rf.y, (lane + s) & 63)};
             }
-            const v2f u = pb_acc(ga, rp, pb_acc(al, rm, v2f(0.0f)));
-            rk = V2{rk.x - (double)u.x, rk.y - (double)u.y};
+            rk32 = rk32 - (ga.bd * v2f(rp.y) + (ga.ac * v2f(rp.x) + (al.bd * v2f(rm.y) + al.ac * v2f(rm.x))));
             al = al_n;
             ga = ga_n;
         }
+        const V2 rk{(double)rk32.x, (double)rk32.y};
         const V2 xk = mvec(Bfin, rk);
         const V2 xk_prev = vprev(xk);
         const v2f se = pb_acc(b_inv, r0, v2f(0.0f)) - pb_acc(b_ic, narrow(xk), pb_acc(b_ia, narrow(xk_prev), v2f(0.0f)));

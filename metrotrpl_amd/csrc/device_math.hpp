@@ -204,11 +204,20 @@ __device__ inline double frcp(double x)
     r = fma(fma(-x, r, 1.0), r, r);
     return r;
 }
+// ... and with one Newton step: the seed of v_rcp_f64 carries about 2^-26, so one step leaves ~1e-15 (measured on
+// gfx950: tests/test_gpu_solver.py::test_rhs_matches_reference).  For the RIGHT-HAND SIDE, evaluated 1300 times per
+// solve; the Jacobian keeps frcp.
+__device__ inline double frcp1(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
 __device__ inline float frcp(float x)
 {
     const float q = __builtin_amdgcn_rcpf(x);
     return fmaf(fmaf(-x, q, 1.0f), q, q);
 }
+__device__ inline float frcp1(float x) { return frcp(x); }
 
 // ---- 2x2 blocks ----------------------------------------------------------------------------------
 template <class T> struct M2T { T a, b, c, d; };

@@ -47,13 +47,13 @@ __device__ inline void edge_flux(const ParT<T> &p, T Nm, T N, T Pm, T P, T E, T 
 template <class T>
 __device__ inline T surface_term(const ParT<T> &p, T S, T N, T P)
 {
-    return S * (N * P - p.n0p0) * frcp(N + P);
+    return S * (N * P - p.n0p0) * frcp1(N + P);
 }
 // bulk recombination ((Cn N + Cp P) + ks + 1/(tn P + tp N)) * (NP - n0p0): forward_solver.py:366
 template <class T>
 __device__ inline T bulk_recomb(const ParT<T> &p, T N, T P, T NP)
 {
-    return ((p.Cn * N + p.Cp * P) + p.ks + frcp((p.tn * P) + (p.tp * N))) * NP;
+    return ((p.Cn * N + p.Cp * P) + p.ks + frcp1((p.tn * P) + (p.tp * N))) * NP;
 }
 // signal density of one node: ks (N P - n0 p0) (forward_solver.py:228-236,:267-269) or
 // q_C (mu_n (N-n0) + mu_p (P-p0)) (:239-247,:272-274)
