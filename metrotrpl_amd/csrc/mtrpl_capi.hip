@@ -439,6 +439,7 @@ const OptD kOptD[] = {
     {"nq_bias_same", &SolveTuning::nq_bias_same}, {"nq_bias_down", &SolveTuning::nq_bias_down},
     {"nq_bias_up", &SolveTuning::nq_bias_up}, {"early_factor", &SolveTuning::early_factor},
     {"early_frac", &SolveTuning::early_frac}, {"hmax_deep", &SolveTuning::hmax_deep},
+    {"hmax_scale", &SolveTuning::hmax_scale},
 };
 const OptI kOptI[] = {
     {"max_steps", &SolveTuning::max_steps}, {"rate_max_age", &SolveTuning::rate_max_age},

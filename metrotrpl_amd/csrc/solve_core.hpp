@@ -76,6 +76,7 @@ struct SolveTuning {
     double e_weight;    // relative error weight of the field components = e_weight * rtol_int (TRPL solves)
     int honor_hmax;     // 1: desc.hmax caps the step (the reference's max_step); 0: error control alone
     double hmax_deep;   // ... until the signal has fallen below this fraction of its first sample (0: always)
+    double hmax_scale;  // the cap is hmax_scale x desc.hmax
     double trts_rtol_factor;  // internal rtol of TRTS solves = this x that of TRPL solves
     double amp_ref;           // > 0: internal rtol /= max(1, (1 + tauP/tauN) / amp_ref); 0: off
     double nq_deadband_hi;    // a step factor in [0.9, this) keeps h and the factors
@@ -95,14 +96,14 @@ struct DefaultTune {
     static constexpr int rate_max_age = 8;
     static constexpr double rate_first_safety = 4.0, e_weight = 3.0;
     static constexpr int honor_hmax = 1;
-    static constexpr double hmax_deep = 1e-11, trts_rtol_factor = 0.5, amp_ref = 16.0, nq_deadband_hi = 1.2;
+    static constexpr double hmax_deep = 1e-11, hmax_scale = 1.0, trts_rtol_factor = 0.5, amp_ref = 16.0, nq_deadband_hi = 1.2;
     static constexpr int nq_rej_memory = 80;
     static constexpr double nq_rej_growth = 1.2, nq_bias_same = 1.0, nq_bias_down = 1.0, nq_bias_up = 1.0;
     static constexpr double early_factor = 10.0, early_frac = 0.5;
     static SolveTuning make()
     {
         return SolveTuning{rtol_scale, rtol_cap, rtol_floor, rtol_min, rtol_force, atol_rel, atol_rel_np, max_steps,
-                           newton_tol, rate_max_age, rate_first_safety, e_weight, honor_hmax, hmax_deep, trts_rtol_factor,
+                           newton_tol, rate_max_age, rate_first_safety, e_weight, honor_hmax, hmax_deep, hmax_scale, trts_rtol_factor,
                            amp_ref, nq_deadband_hi, nq_rej_memory, nq_rej_growth, nq_bias_same, nq_bias_down, nq_bias_up,
                            early_factor, early_frac};
     }
@@ -231,7 +232,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
     bk.set_problem(make_par<real>(ds.par, dx), L);
     const ParT<real> &p = bk.p;
     const double *ts = tsteps + ds.t_off;
-    const real hmax = tune.honor_hmax ? (real)ds.hmax : big<real>();
+    const real hmax = tune.honor_hmax ? (real)(ds.hmax * tune.hmax_scale) : big<real>();
     const ctl inv_S = (ctl)(1.0 / (double)((TRAPS ? 4 : 3) * L + 1));
     bk.out_begin(out + ds.out_off, ds.min_y, (meas == MTRPL_MEAS_TRPL) ? 1e23 : 1e9, tune.hmax_deep);  // forward_solver.py:189,:197
     const int lane64 = (int)(threadIdx.x & 63);

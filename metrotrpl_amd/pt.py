@@ -3,7 +3,8 @@
 What the reference does with one MPI rank per chain and point-to-point sends
 (metropolis.py:140-267: bcast of the pair index, send/recv of -log_ri, of the
 accept flag, of two log-likelihoods and two state vectors per accepted swap) is
-done here with ONE collective per iteration:
+done here with ONE collective per replica exchange (history-free "counter" draws, the mode the ensembles of
+bench.py run in) or per iteration (draws in the reference's program order, "stream"):
 
   * chains are block-partitioned over the ranks (`partition`), all measurements
     of a chain stay on one GPU, so the per-chain log-likelihood is local;
@@ -12,13 +13,19 @@ done here with ONE collective per iteration:
     (trial_move_evaluation.py:150-156), so a scalar per chain is not enough for a
     sequence of swaps -- and an all-gather (RCCL over xGMI; `gloo` in the CPU
     tests) assembles the [n_chains x n_T] table on every rank;
-  * proposals, Metropolis accept/reject (metropolis.py:42-63) and the
-    `n_chains - 1` sequential random adjacent swap attempts
+  * the `n_chains - 1` sequential random adjacent swap attempts
     (metropolis.py:66-90, :129-135) are REPLAYED identically on every rank from a
     shared-seed generator: no further traffic, swapped states move as index
-    permutations of the (replicated, tiny) host-side state array, and the new
-    log-likelihood of a swapped chain is looked up in the table instead of being
-    re-simulated as the reference does (metropolis.py:87-88).
+    permutations of the gathered state array, and the new log-likelihood of a
+    swapped chain is looked up in the table instead of being re-simulated as the
+    reference does (metropolis.py:87-88);
+  * BETWEEN two exchanges the chains do not interact.  With counter-mode draws chain c only ever
+    sees row c of a draw, so a rank proposes and decides (metropolis.py:42-63) for its OWN block only:
+    the log-likelihood rows of its current states stay on the device, one number per proposal (its
+    log-likelihood at the chain's own temperature) comes back to the host, and nothing crosses the
+    ranks until the next exchange gathers [own rows x (n_T + n_params)] once.  In "stream" mode every
+    draw comes out of one generator in program order, so every rank has to replay every chain to stay
+    in step with it, and the table is gathered at every iteration as before.
 
 Host logic only (numpy + torch.distributed); the evaluator is injected.
 """
@@ -232,15 +239,22 @@ class PTEnsemble:
     group (below).
 
     rng_mode "stream": every draw comes from one shared-seed generator in program order, like the
-    reference's walk (metropolis.py:296).  rng_mode "counter": the draws of iteration k for purpose w
-    (proposal / accept roll / swaps) come from a Philox generator keyed by (seed, k, w) -- they do not
-    depend on how many numbers earlier iterations consumed.  That buys two things, both walking exactly the
-    chain the one-iteration-at-a-time run walks:
+    reference's walk (metropolis.py:296); every rank replays every chain and the table is all-gathered at
+    every iteration.  rng_mode "counter": the draws of iteration k for purpose w (proposal / accept roll /
+    swaps) come from a Philox generator keyed by (seed, k, w) -- they do not depend on how many numbers
+    earlier iterations consumed, and chain c only ever uses row c of a draw.  That buys three things, all
+    walking exactly the chain the one-iteration-at-a-time, one-rank run walks:
+      * local decisions: a rank proposes and accepts / rejects for its own chain block only; the ranks
+        exchange [own rows x (n_T + n_params)] ONCE per replica exchange (`sync`), not per iteration, and
+        between exchanges only one number per proposal leaves the device;
       * prefetching: the proposals of iteration k+1 for BOTH outcomes of iteration k are evaluated in the
         same launch as iteration k's (a GPU with idle SIMDs does two iterations in one solve latency);
       * chain groups: between two replica exchanges the chains do not interact, so the ensemble is cut into
         `groups` interleaved sets (chain c in group c % groups), each with its own evaluator and HIP stream;
-        while the host decides and re-proposes for one group, the other group's launch is on the GPU."""
+        while the host decides and re-proposes for one group, the other group's launch is on the GPU.
+
+    In counter mode `states`, `logll` and `table` are complete on every rank after `initialise`, after a
+    replica exchange and after `advance` / `sync`; in between a rank keeps only its own rows current."""
 
     def __init__(self, states, temperatures, evaluator, rank=0, world=1, seed=235817049752375780, group=None,
                  rng_mode="stream", streams=None):
@@ -261,7 +275,10 @@ class PTEnsemble:
         self.sel = [np.arange(g, self.n, self.groups) for g in range(self.groups)]
         self.gblocks = [[(int(np.searchsorted(sel, lo)), int(np.searchsorted(sel, hi))) for lo, hi in self.blocks]
                         for sel in self.sel]
+        # ... and this rank's own chains of group g (global indices)
+        self.own = [sel[a:b] for sel, (a, b) in zip(self.sel, (gb[rank] for gb in self.gblocks))]
         self.rng_mode = rng_mode
+        self.local = rng_mode == "counter"  # propose / decide for the own block only, gather at exchanges
         self.seed = int(seed)
         self.rng = np.random.default_rng(seed)  # metropolis.py:296 (same seed on every rank, :410-411)
         self._philox = None
@@ -270,6 +287,9 @@ class PTEnsemble:
         self.pending = {}
         self.table = None
         self.logll = None
+        self.cur_tab = None                       # device: table rows of this rank's current states [hi - lo, nT]
+        self.acc_count = np.zeros(self.n, dtype=np.int64)  # accepted moves per chain (own rows current)
+        self.n_collectives = 0                    # all-gathers issued so far
         self.swap_attempts = np.zeros(self.n, dtype=np.int64)
         self.swap_accepts = np.zeros(self.n, dtype=np.int64)
 
@@ -298,12 +318,79 @@ class PTEnsemble:
         bg.state = st
         return gen
 
+    def _collective(self):
+        """Does a gather go through torch.distributed (more than one rank, or a one-rank group that was set up)?"""
+        import torch.distributed as dist
+        return self.world > 1 or (dist.is_available() and dist.is_initialized())
+
     def gather_table(self, states):
         """Evaluate the local block at all ladder temperatures, all-gather -> [n, nT] numpy."""
+        self.n_collectives += int(self._collective())
         return gather_ll_table(self.evaluators[0], states, self.T, self.blocks, self.rank, self.world, self.group)
 
     def initialise(self):
-        self.table = self.gather_table(self.states)
+        if not self.local:
+            self.table = self.gather_table(self.states)
+            self.logll = self.table[np.arange(self.n), np.arange(self.n)].copy()
+            return
+        self.cur_tab = self.evaluators[0](self.states[self.lo:self.hi], self.T).clone()
+        self.logll = np.zeros(self.n)
+        self.sync()
+
+    # ---- counter mode: what crosses the ranks, once per replica exchange ----------------------------
+    def sync(self):
+        """All-gather [own rows x (n_T + n_params + 1)] = the log-likelihood rows of the current states (from the
+        device), the states and the per-chain accept counts: afterwards `table`, `states`, `logll` and
+        `acc_count` are complete and identical on every rank.  One collective."""
+        import torch
+        import torch.distributed as dist
+        if not self.local:
+            return
+        for st in self.streams:  # the decisions of every group have been applied to cur_tab on its stream
+            if st is not None:
+                st.synchronize()
+        c, nT, npar = self.hi - self.lo, self.T.shape[0], self.states.shape[1]
+        dev = self.cur_tab.device
+        host = np.concatenate([self.states[self.lo:self.hi], self.acc_count[self.lo:self.hi, None].astype(np.float64)], axis=1)
+        single = self.world == 1 and not (dist.is_available() and dist.is_initialized())
+        if single:
+            self.table = self.cur_tab.detach().cpu().numpy().copy()
+            self._sync_logll()
+            return
+        mx = max(b[1] - b[0] for b in self.blocks)
+        send = torch.zeros((mx, nT + npar + 1), dtype=torch.float64, device=dev)
+        send[:c, :nT] = self.cur_tab
+        send[:c, nT:] = torch.from_numpy(host).to(dev)
+        recv = torch.empty((self.world * mx, nT + npar + 1), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        self.n_collectives += 1
+        arr = recv.cpu().numpy().reshape(self.world, mx, nT + npar + 1)
+        full = np.concatenate([arr[r, :b[1] - b[0]] for r, b in enumerate(self.blocks)], axis=0)
+        self.table = np.ascontiguousarray(full[:, :nT])
+        self.states = np.ascontiguousarray(full[:, nT:nT + npar])
+        self.acc_count = np.rint(full[:, -1]).astype(np.int64)
+        self.logll = self.table[np.arange(self.n), np.arange(self.n)].copy()
+
+    def _dev_cache(self, g, G):
+        """Index tensors and mask staging of group g's launches, built ONCE on the device: nothing in the hot
+        path copies from pageable host memory (such a copy makes the host wait for the stream's queued kernels,
+        i.e. for the whole solve, and the launches of the chain groups no longer overlap)."""
+        import torch
+        key = (g, G)
+        c = getattr(self, "_devc", None)
+        if c is None:
+            c = self._devc = {}
+        if key not in c:
+            dev = self.cur_tab.device
+            sel = self.own[g]
+            pin = dev.type == "cuda"
+            c[key] = {"col": torch.from_numpy(np.tile(sel, G)).to(dev),
+                      "rows": torch.from_numpy(np.ascontiguousarray(sel - self.lo)).to(dev),
+                      "mask_host": torch.zeros((2, max(1, sel.shape[0])), dtype=torch.bool, pin_memory=pin),
+                      "mask_dev": torch.zeros((2, max(1, sel.shape[0])), dtype=torch.bool, device=dev)}
+        return c[key]
+
+    def _sync_logll(self):
         self.logll = self.table[np.arange(self.n), np.arange(self.n)].copy()
 
     # ---- one group, one launch: propose + enqueue, then decide --------------------------------------
@@ -311,19 +398,25 @@ class PTEnsemble:
         """Propose the next `depth` (1 or 2) iterations of group g and enqueue their evaluation: per chain
         the proposal of iteration it+1 and, for depth 2, the two proposals it+2 can make -- from the current
         state if it+1 rejects, from the it+1 proposal if it accepts."""
-        sel, it = self.sel[g], self.git[g]
+        it = self.git[g]
+        sel = self.own[g] if self.local else self.sel[g]
         xs, Ts = self.states[sel], self.T[sel]
-        whole = self.groups == 1
+        whole = self.groups == 1 and not self.local
 
         def rows(i):
             rng = self.draws(i, PROPOSE)
             return rng if whole else _Rows(rng, self.n, sel)
-        y1 = proposer(xs, Ts, rows(it + 1))
+        y1 = proposer(xs, Ts, rows(it + 1)) if sel.shape[0] else xs.copy()
         props = [y1]
         if depth == 2:
             if self.rng_mode != "counter":
                 raise RuntimeError("prefetching needs rng_mode='counter'")
-            props += [proposer(xs, Ts, rows(it + 2)), proposer(y1, Ts, rows(it + 2))]
+            props += [proposer(xs, Ts, rows(it + 2)), proposer(y1, Ts, rows(it + 2))] if sel.shape[0] else [xs.copy(), xs.copy()]
+        if self.local:
+            self.pending[g] = (depth, props, _LocalEval(self.evaluators[g], props, self.T, sel, self.streams[g],
+                                                        self._dev_cache(g, len(props))))
+            return
+        self.n_collectives += int(self._collective())
         gather = TableGather(self.evaluators[g], props, self.T, self.gblocks[g], self.rank, self.world, self.group,
                              self.streams[g])
         self.pending[g] = (depth, props, gather)
@@ -338,26 +431,58 @@ class PTEnsemble:
         self.states[idx] = new_states[acc]
         self.table[idx] = new_table[acc]
         self.logll[idx] = new_ll[acc]
+        self.acc_count[idx] += 1
         return acc
 
     def _end(self, g):
-        depth, props, gather = self.pending.pop(g)
-        tabs = gather.tables()
+        depth, props, ev = self.pending.pop(g)
         it = self.git[g]
-        accs = [self._displace(g, it + 1, props[0], tabs[0])]
+        if not self.local:
+            tabs = ev.tables()
+            accs = [self._displace(g, it + 1, props[0], tabs[0])]
+            if depth == 2:
+                a = accs[0][:, None]
+                accs.append(self._displace(g, it + 2, np.where(a, props[2], props[1]), np.where(a, tabs[2], tabs[1])))
+            self.git[g] = it + depth
+            return accs
+        # own block only: the proposals' log-likelihoods at the chains' own temperatures decide; the table rows
+        # of the accepted ones replace the current rows ON THE DEVICE
+        sel = self.own[g]
+        lls = ev.own_ll()  # [depth == 2 ? 3 : 1][c]
+        a1 = metropolis_accept(self.logll[sel], lls[0], self.draws(it + 1, ACCEPT), (self.n, sel))
+        self.states[sel[a1]] = props[0][a1]
+        self.logll[sel[a1]] = lls[0][a1]
+        self.acc_count[sel[a1]] += 1
+        accs, masks = [a1], [a1]
         if depth == 2:
-            a = accs[0][:, None]
-            accs.append(self._displace(g, it + 2, np.where(a, props[2], props[1]), np.where(a, tabs[2], tabs[1])))
+            ll2 = np.where(a1, lls[2], lls[1])
+            p2 = np.where(a1[:, None], props[2], props[1])
+            a2 = metropolis_accept(self.logll[sel], ll2, self.draws(it + 2, ACCEPT), (self.n, sel))
+            self.states[sel[a2]] = p2[a2]
+            self.logll[sel[a2]] = ll2[a2]
+            self.acc_count[sel[a2]] += 1
+            accs.append(a2)
+            masks.append(a2)
+        ev.apply(self.cur_tab, sel - self.lo, masks)
         self.git[g] = it + depth
-        return accs
+        full = []
+        for a in accs:  # in the shape the replicated mode returns: one flag per chain of the group (own rows set)
+            f = np.zeros(self.sel[g].shape[0], dtype=bool)
+            f[self.gblocks[g][self.rank][0]:self.gblocks[g][self.rank][1]] = a
+            full.append(f)
+        return full
 
     def _exchange(self, it):
+        self.sync()
         owner, att, accs = replica_exchange(self.table, self.draws(it, SWAP))
         self.states = self.states[owner]
         self.table = self.table[owner]
-        self.logll = self.table[np.arange(self.n), np.arange(self.n)].copy()
+        self._sync_logll()
         self.swap_attempts += att
         self.swap_accepts += accs
+        if self.local:
+            import torch
+            self.cur_tab.copy_(torch.from_numpy(np.ascontiguousarray(self.table[self.lo:self.hi])))
 
     def _all_groups(self, proposer, depth, do_swap):
         for g in range(self.groups):
@@ -375,13 +500,14 @@ class PTEnsemble:
         return out
 
     def iterate(self, proposer, do_swap):
-        """One Metropolis iteration for every chain (+ replica exchange if do_swap)."""
+        """One Metropolis iteration for every chain (+ replica exchange if do_swap).  -> accept flags per chain
+        (counter mode: of this rank's own chains, False elsewhere)."""
         return self._all_groups(proposer, 1, do_swap)[0]
 
     def iterate2(self, proposer, do_swap):
-        """Two iterations from ONE evaluator launch and ONE collective per group (no replica exchange between
-        them; `do_swap`: exchange after the second); one of the two speculative evaluations per chain is
-        discarded.  Same chain as two `iterate` calls (counter mode only)."""
+        """Two iterations from ONE evaluator launch per group (no replica exchange between them; `do_swap`:
+        exchange after the second); one of the two speculative evaluations per chain is discarded.  Same chain
+        as two `iterate` calls (counter mode only)."""
         if self.rng_mode != "counter":
             raise RuntimeError("iterate2 needs rng_mode='counter'")
         return tuple(self._all_groups(proposer, 2, do_swap))
@@ -390,8 +516,10 @@ class PTEnsemble:
         """`n_iters` iterations with a replica exchange after every `temper_freq`-th (metropolis.py:129).
         Between two exchanges every chain group runs at its own pace: with `prefetch` two iterations per
         launch, and with several groups the launch of one overlaps the host work of the others.
-        -> accepted moves."""
+        -> accepted moves of the whole ensemble (counter mode: `states`, `logll`, `table` are complete again on
+        return)."""
         n_acc, stop = 0, self.it + n_iters
+        acc0 = int(self.acc_count.sum())
         while self.it < stop:
             seg_end = min(stop, (self.it // temper_freq + 1) * temper_freq)  # next exchange or the end
             depth = lambda g: 2 if prefetch and seg_end - self.git[g] >= 2 else 1  # noqa: E731
@@ -407,4 +535,71 @@ class PTEnsemble:
             self.it = seg_end
             if seg_end % temper_freq == 0:
                 self._exchange(seg_end)
+        if self.local:
+            if stop % temper_freq != 0:
+                self.sync()
+            return int(self.acc_count.sum()) - acc0
         return n_acc
+
+
+class _LocalEval:
+    """Counter mode, one launch of one chain group on this rank: the evaluator's kernels for the proposals of the
+    rank's own chains (enqueued on `stream` when given) and the copy of ONE number per proposal -- its
+    log-likelihood at the chain's own temperature -- to pinned host memory.  The [rows x nT] tables stay on the
+    device; `apply` moves the accepted rows into the rank's current-table tensor there.  `cache`: the index
+    tensors and the pinned mask staging of this group (PTEnsemble._dev_cache)."""
+
+    def __init__(self, evaluator, props, temperatures, sel, stream, cache):
+        import torch
+        self.c, self.G, self.stream, self.cache = sel.shape[0], len(props), stream, cache
+        self.event, self.dev_tab = None, None
+        if self.c == 0:
+            self.host = None
+            return
+        block = props[0] if self.G == 1 else np.concatenate(props, axis=0)
+        with (torch.cuda.stream(stream) if stream is not None else _Nothing()):
+            tab = evaluator(block, temperatures)  # [G * c, nT]
+            self.dev_tab = tab
+            diag = tab.gather(1, cache["col"][:, None])[:, 0]
+            if diag.is_cuda:
+                key = ((self.G * self.c,), diag.dtype)
+                free = _PINNED.setdefault(key, [])
+                self.pool_key = key
+                self.host = free.pop() if free else torch.empty(key[0], dtype=diag.dtype, pin_memory=True)
+                self.host.copy_(diag, non_blocking=True)
+                self.event = torch.cuda.Event()
+                self.event.record(stream if stream is not None else torch.cuda.current_stream())
+            else:
+                self.host = diag
+
+    def own_ll(self):
+        if self.c == 0:
+            return [np.zeros(0)] * self.G
+        if self.event is not None:
+            self.event.synchronize()
+            arr = self.host.numpy().copy()
+            _PINNED[self.pool_key].append(self.host)
+        else:
+            arr = self.host.numpy()
+        return [arr[g * self.c:(g + 1) * self.c] for g in range(self.G)]
+
+    def apply(self, cur_tab, rows, masks):
+        """cur_tab[rows] <- table row of the accepted proposal: iteration 1 takes props[0] where masks[0]; iteration
+        2 (prefetched) takes props[2] where masks[0] else props[1], where masks[1]."""
+        import torch
+        if self.c == 0:
+            return
+        with (torch.cuda.stream(self.stream) if self.stream is not None else _Nothing()):
+            mh, md, idx = self.cache["mask_host"], self.cache["mask_dev"], self.cache["rows"]
+            # (the previous launch of this group has been decided, i.e. its mask copy has been consumed: the event
+            # its decision waited for sits behind that copy on the same stream)
+            mh[0, :self.c] = torch.from_numpy(np.ascontiguousarray(masks[0]))
+            if len(masks) == 2:
+                mh[1, :self.c] = torch.from_numpy(np.ascontiguousarray(masks[1]))
+            md.copy_(mh, non_blocking=True)
+            t = self.dev_tab.view(self.G, self.c, -1)
+            m1 = md[0, :self.c, None]
+            cur = torch.where(m1, t[0], cur_tab[idx])
+            if len(masks) == 2:
+                cur = torch.where(md[1, :self.c, None], torch.where(m1, t[2], t[1]), cur)
+            cur_tab[idx] = cur

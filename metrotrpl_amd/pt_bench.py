@@ -2,12 +2,12 @@
 ensemble on the staub 6-measurement power scan (lengths 311/2000 nm x 3 fluences,
 nx=128, 1001 sample times, IRF convolution with a 189-tap IRF, ladder
 T_k = 1000^(k/(n-1))), chains block-partitioned over the ranks (strong scaling),
-one RCCL all-gather of the per-chain log-likelihood table per iteration.
+one RCCL all-gather of the per-chain log-likelihood table (and the states) per replica exchange.
 
 One "step" = one Metropolis iteration of the whole ensemble: propose for every
 chain, n_chains x 6 forward solves + IRF convolutions + likelihoods at all ladder
-temperatures on the GPUs, all-gather, accept/reject, and (every temper_freq
-iterations, SURVEY.md 8d: 10) the replica-exchange replay.
+temperatures on the GPUs, accept/reject of the rank's own chains, and (every temper_freq
+iterations, SURVEY.md 8d: 10) the all-gather + replica-exchange replay.
 """
 import json
 import os
@@ -124,6 +124,7 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
     if getattr(a, "use_dist", world > 1):
         dist.barrier()
     torch.cuda.synchronize()
+    coll0 = ens.n_collectives
     t0 = time.perf_counter()
     n_acc = ens.advance(proposer, a.steps, temper_freq, prefetch)
     torch.cuda.synchronize()
@@ -142,9 +143,11 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"config3/4: {n_chains} PT chains x 6-measurement staub power scan, nx=128, 1001 times, "
                                "IRF convolution (189 taps, dt 0.025 ns) + likelihood at all ladder temperatures on "
-                               "device, all-gather of the ll table every iteration, swaps every 10",
+                               "device; every rank proposes and decides for its own chain block, one all-gather of [own rows x "
+                               "(n_T + n_params)] per replica exchange (every 10 iterations)",
                    "chains": n_chains, "solves_per_step": n_chains * 6, "parallelism": f"chain-blocks x{world}",
                    "prefetch": bool(prefetch), "chain_groups": groups,
+                   "collectives_per_iteration": (ens.n_collectives - coll0) / max(1, a.steps),
                    "forward_solves_per_sec": n_chains * 6 * a.steps / dt, "accepted_moves": n_acc,
                    "swap_accept_rate": float(ens.swap_accepts.sum() / max(1, ens.swap_attempts.sum())),
                    "mean_integrator_steps_rank0": float(stats[:, 0].mean()),

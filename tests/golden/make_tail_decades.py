@@ -11,7 +11,12 @@ less, where 1e-17 is a 1e-5 relative error per step (measured: 2e-3 off at the 8
 through zero and needs an absolute floor, 1e-24 there makes LSODA crawl.  1e-24 vs 1e-21 on the densities
 agree to 1e-6 at the 8th decade.
 
-    python tests/golden/make_tail_decades.py            (about 3 minutes on 8 cores)
+The oracle's OWN uncertainty is stored next to the traces: the same solves at two perturbed
+settings -- density ATOL 1e-26 instead of 1e-24, and RTOL 3e-13 instead of 1e-12 -- and, per trace and per decade of
+signal decay, the largest relative difference of either from the primary trace (`u_oracle[trace, decade]`,
+decades 0..12).  A GPU error below 1e-6 + u_oracle cannot be told from an oracle error.
+
+    python tests/golden/make_tail_decades.py            (about 10 minutes on 8 cores)
 """
 import os
 import sys
@@ -30,12 +35,21 @@ e = W.pt_ensemble(NCH)
 ix, un = W.indexes(), W.units()
 
 
-def one(k):
+SETTINGS = [(1e-12, 1e-24), (1e-12, 1e-26), (3e-13, 1e-24)]  # (RTOL, density ATOL); the first is the fixture's trace
+
+
+def one(job):
     from oracle import oracle as O
+    k, (rtol, atol_np) = job
     src, th, j = (c, 2000.0, k) if k < N2 else (e, float(e["thickness"][k - N2]), k - N2)
     g = O.Grid(th, 128, src["tSteps"], 4.0)
-    return O.solve(src["iniPar"][j], g, src["states"][j], ix, units=un, ini_mode="fluence", RTOL=1e-12,
-                   ATOL=np.r_[np.full(256, 1e-24), np.full(129, 1e-17)])
+    return O.solve(src["iniPar"][j], g, src["states"][j], ix, units=un, ini_mode="fluence", RTOL=rtol,
+                   ATOL=np.r_[np.full(256, atol_np), np.full(129, 1e-17)])
+
+
+def decade_of(ref):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.clip(np.floor(np.log10(np.abs(ref[:, :1])) - np.log10(np.maximum(np.abs(ref), 1e-300))).astype(int), 0, 12)
 
 
 if __name__ == "__main__":
@@ -44,8 +58,18 @@ if __name__ == "__main__":
     from oracle import oracle as O
     O.build()
     with Pool(min(8, os.cpu_count() or 1)) as p:
-        sig = np.array(p.map(one, range(n), chunksize=2))
-    np.savez_compressed(os.path.join(HERE, "tail_decades.npz"),
+        sigs = [np.array(p.map(one, [(k, st) for k in range(n)], chunksize=2)) for st in SETTINGS]
+    sig = sigs[0]
+    dec = decade_of(sig)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        spread = np.maximum(np.abs(sigs[1] - sig), np.abs(sigs[2] - sig)) / np.abs(sig)
+    u = np.zeros((n, 13))
+    for d in range(13):
+        m = dec == d
+        u[:, d] = np.where(m.any(axis=1), np.where(m, spread, 0.0).max(axis=1), 0.0)
+    print("oracle self-uncertainty, max over traces per decade:", " ".join(f"{v:.1e}" for v in u.max(axis=0)))
+    np.savez_compressed(os.path.join(HERE, "tail_decades.npz"), u_oracle=u,
+                        u_oracle_settings=np.array("max over (RTOL 1e-12, density ATOL 1e-26) and (RTOL 3e-13, density ATOL 1e-24) of |trace - primary| / |primary|, per trace and decade 0..12"),
                         states=np.concatenate([c["states"], e["states"]]), iniPar=np.concatenate([c["iniPar"], e["iniPar"]]),
                         thickness=np.concatenate([np.full(N2, 2000.0), e["thickness"]]), sig=sig, tSteps=c["tSteps"],
                         n_cfg2=N2, names=np.array(",".join(W.PARAM_NAMES)), units=un)

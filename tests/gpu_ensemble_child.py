@@ -1,7 +1,8 @@
 """Child process of tests/test_gpu_ensemble.py: the config-3 parallel-tempering ensemble (64 chains x the
 6-measurement staub power scan, nx=128, 1001 sample times, IRF 745 nm) for a few iterations on cuda:0,
 optionally inside a one-rank `nccl` process group that is initialised BEFORE anything touches the GPU, so
-that the per-iteration all-gather of the log-likelihood table really goes through RCCL.
+that the all-gather of the log-likelihood table (per iteration with stream-mode draws, per replica exchange with
+counter-mode draws) really goes through RCCL.
 Writes the walk to an .npz.  Not a test by itself."""
 import argparse
 import os
@@ -56,7 +57,7 @@ def main():
     np.savez(a.out, states0=S["ens0"]["chain_states"], table0=table0, states=ens.states, logll=ens.logll, table=ens.table,
              swap_attempts=ens.swap_attempts, swap_accepts=ens.swap_accepts, T=S["T"], times=S["times"],
              vals=np.array(S["vals"]), uncs=np.array(S["uncs"]), n_parts=n_parts, swaps=swaps, backend=np.array(backend),
-             ordered=np.array(S["eng"]._order is not None), calls=np.array(calls), n_acc=n_acc)
+             ordered=np.array(S["eng"]._order is not None), calls=np.array(calls), n_acc=n_acc, n_collectives=ens.n_collectives)
     if a.dist:
         dist.destroy_process_group()
 

@@ -52,6 +52,7 @@ def test_config3_ensemble_through_rccl_and_two_streams(tmp_path):
     assert str(a["backend"]) == "nccl" and str(c["backend"]) == "nccl" and str(b["backend"]) == "none"
     assert int(a["n_parts"]) == 2 and int(b["n_parts"]) == 1 and bool(a["ordered"]) and not bool(b["ordered"])
     assert int(a["swaps"]) == 2 and a["swap_attempts"].sum() == 2 * 63
+    assert int(a["n_collectives"]) == 1 + 12  # stream-mode draws: the table is gathered at every iteration
     assert a["states"].shape == (64, len(W.PARAM_NAMES))
     # (b) the same walk whatever the plumbing: states, log-likelihoods, the whole table, swap decisions
     for other in (b, c):
@@ -87,6 +88,9 @@ def test_prefetched_ensemble_walks_the_same_chain(tmp_path):
                  port=29619)
     assert list(one["calls"]) == [64] * 12 and list(two["calls"]) == [192] * 6
     assert str(two["backend"]) == "nccl" and bool(two["ordered"])
+    # counter-mode draws: the ranks exchange at replica-exchange steps only -- one all-gather at initialise and one
+    # per exchange (iterations 4, 8, 12), through RCCL; the run without a process group issues none
+    assert int(two["n_collectives"]) == 1 + 3 and int(one["n_collectives"]) == 0
     for key in ("states", "logll", "table", "swap_attempts", "swap_accepts", "n_acc"):
         np.testing.assert_array_equal(one[key], two[key], err_msg=key)
     assert int(one["n_acc"]) > 0 and one["swap_attempts"].sum() == 3 * 63

@@ -161,15 +161,16 @@ def _prefetch_worker(rank, world, port, n_chains, iters, groups, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     e, n_acc, _ = _run_counter(n_chains, iters, True, rank, world, groups=groups)
-    q.put((rank, e.states.copy(), e.logll.copy(), e.swap_accepts.copy(), n_acc))
+    q.put((rank, e.states.copy(), e.logll.copy(), e.swap_accepts.copy(), n_acc, e.n_collectives, e.table.copy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,n_chains,groups", [(2, 8, 1), (3, 8, 1), (2, 8, 2), (3, 7, 2)])
 def test_prefetched_sharded_ensemble_equals_serial(world, n_chains, groups):
-    """Three proposal sets per launch through ONE all-gather (even and uneven chain blocks), whole and in
-    chain groups."""
+    """Counter-mode draws: every rank proposes and decides for its own chain block only (three proposal sets per
+    launch when prefetching) and the ranks exchange ONCE per replica exchange -- even and uneven chain blocks,
+    whole and in chain groups: the walk of the one-rank, one-iteration-at-a-time run, bit for bit."""
     iters = 11
     ref, acc_ref, _ = _run_counter(n_chains, iters, False)
     ctx = mp.get_context("spawn")
@@ -183,11 +184,20 @@ def test_prefetched_sharded_ensemble_equals_serial(world, n_chains, groups):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for _, states, logll, swaps, n_acc in res:
+    for _, states, logll, swaps, n_acc, n_coll, table in res:
         np.testing.assert_array_equal(states, ref.states)
         np.testing.assert_array_equal(logll, ref.logll)
+        np.testing.assert_array_equal(table, ref.table)
         np.testing.assert_array_equal(swaps, ref.swap_accepts)
         assert n_acc == acc_ref
+        # one all-gather at initialise, one per replica exchange (iterations 4 and 8), one to complete the
+        # replicated view after the last iteration: NOT one per iteration
+        assert n_coll == 1 + iters // 4 + 1
+    # what the walk carries is what the evaluator says about the states it ended on
+    want = _toy_evaluator(ref.states, ref.T).numpy()
+    np.testing.assert_array_equal(ref.table, want)
+    np.testing.assert_array_equal(ref.logll, np.diag(want))
+    assert acc_ref == int(ref.acc_count.sum()) > 0
 
 
 def test_partition():

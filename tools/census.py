@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 from metrotrpl_amd import workloads as W, batch, _lib as L
 MEAS = os.environ.get("CENSUS_MEAS", "TRPL")
 TAG = os.environ.get("CENSUS_TAG", "")
-z = np.load(os.path.join(ROOT, "tools", "_cache", ("census_refs" if MEAS == "TRPL" else f"census_refs_{MEAS.lower()}") + TAG + ".npz"))
+z = np.load(os.path.join(ROOT, "tools", "census_cache", ("census_refs" if MEAS == "TRPL" else f"census_refs_{MEAS.lower()}") + TAG + ".npz"))
 N, NCH = int(z["n"]), int(z["nch"])
 c = W.config2(N); e = W.pt_ensemble(NCH); c2 = W.config2(1024)
 ix, un = W.indexes(), W.units()
