@@ -434,12 +434,13 @@ const OptD kOptD[] = {
     {"rtol_force", &SolveTuning::rtol_force},
     {"atol_rel", &SolveTuning::atol_rel}, {"atol_rel_np", &SolveTuning::atol_rel_np}, {"newton_tol", &SolveTuning::newton_tol},
     {"rate_first_safety", &SolveTuning::rate_first_safety}, {"e_weight", &SolveTuning::e_weight},
-    {"trts_rtol_factor", &SolveTuning::trts_rtol_factor}, {"amp_ref", &SolveTuning::amp_ref},
+    {"trts_rtol_factor", &SolveTuning::trts_rtol_factor}, {"amp_ref", &SolveTuning::amp_ref}, {"amp_post", &SolveTuning::amp_post},
     {"nq_deadband_hi", &SolveTuning::nq_deadband_hi}, {"nq_rej_growth", &SolveTuning::nq_rej_growth},
     {"nq_bias_same", &SolveTuning::nq_bias_same}, {"nq_bias_down", &SolveTuning::nq_bias_down},
     {"nq_bias_up", &SolveTuning::nq_bias_up}, {"early_factor", &SolveTuning::early_factor},
     {"early_frac", &SolveTuning::early_frac}, {"hmax_deep", &SolveTuning::hmax_deep},
-    {"hmax_scale", &SolveTuning::hmax_scale},
+    {"hmax_scale", &SolveTuning::hmax_scale}, {"tail_frac", &SolveTuning::tail_frac}, {"tail_factor", &SolveTuning::tail_factor},
+    {"far_frac", &SolveTuning::far_frac}, {"far_factor", &SolveTuning::far_factor},
 };
 const OptI kOptI[] = {
     {"max_steps", &SolveTuning::max_steps}, {"rate_max_age", &SolveTuning::rate_max_age},

@@ -77,8 +77,16 @@ struct SolveTuning {
     int honor_hmax;     // 1: desc.hmax caps the step (the reference's max_step); 0: error control alone
     double hmax_deep;   // ... until the signal has fallen below this fraction of its first sample (0: always)
     double hmax_scale;  // the cap is hmax_scale x desc.hmax
+    double tail_frac;   // once the signal has fallen below this fraction of its first sample ...
+    double tail_factor; // ... the local tolerance is multiplied by this (< 1: the relative error of a long decay
+                        // accumulates per e-fold; the deep decades of a trace need the error budget of the shallow ones)
+    double far_frac;    // ... and below this fraction by far_factor instead (> 1: nine decades down nothing resolves
+    double far_factor;  // the signal any more -- measured traces span four to five -- and the slowest solves of a
+                        // batch are the ones that crawl through decades 9 to 17)
     double trts_rtol_factor;  // internal rtol of TRTS solves = this x that of TRPL solves
-    double amp_ref;           // > 0: internal rtol /= max(1, (1 + tauP/tauN) / amp_ref); 0: off
+    double amp_ref;           // > 0: local tolerance /= max(1, (1 + tauP/tauN) / amp_ref) ...; 0: off
+    double amp_post;          // ... until the excess density has fallen below amp_post x p0 (judged by the emitted signal):
+                              // from there on the decay is low-injection and nothing amplifies an error any more
     double nq_deadband_hi;    // a step factor in [0.9, this) keeps h and the factors
     int nq_rej_memory; double nq_rej_growth;  // growth cap for this many steps after a rejection
     double nq_bias_same, nq_bias_down, nq_bias_up;  // multipliers of the step factors (stode: 1/1.2, 1/1.3, 1/1.4)
@@ -90,21 +98,21 @@ struct SolveTuning {
 // run-time struct keeps none of them in (spilled) scalar registers.  Single source of the defaults.
 struct DefaultTune {
     static constexpr double rtol_scale = 0.1, rtol_cap = 3e-9, rtol_floor = 3e-10, rtol_min = 3e-11, rtol_force = 0.0;
-    static constexpr double atol_rel = 1e-4, atol_rel_np = 1e-8;
+    static constexpr double atol_rel = 1e-4, atol_rel_np = 1e-9;
     static constexpr int max_steps = 2000000;
     static constexpr double newton_tol = 0.1;
     static constexpr int rate_max_age = 8;
     static constexpr double rate_first_safety = 4.0, e_weight = 3.0;
     static constexpr int honor_hmax = 1;
-    static constexpr double hmax_deep = 1e-11, hmax_scale = 1.0, trts_rtol_factor = 0.5, amp_ref = 16.0, nq_deadband_hi = 1.2;
+    static constexpr double hmax_deep = 1e-11, hmax_scale = 1.0, tail_frac = 1e-4, tail_factor = 0.4, far_frac = 1e-9, far_factor = 3.0, trts_rtol_factor = 0.5, amp_ref = 10.0, amp_post = 0.03, nq_deadband_hi = 1.2;
     static constexpr int nq_rej_memory = 80;
     static constexpr double nq_rej_growth = 1.2, nq_bias_same = 1.0, nq_bias_down = 1.0, nq_bias_up = 1.0;
     static constexpr double early_factor = 10.0, early_frac = 0.5;
     static SolveTuning make()
     {
         return SolveTuning{rtol_scale, rtol_cap, rtol_floor, rtol_min, rtol_force, atol_rel, atol_rel_np, max_steps,
-                           newton_tol, rate_max_age, rate_first_safety, e_weight, honor_hmax, hmax_deep, hmax_scale, trts_rtol_factor,
-                           amp_ref, nq_deadband_hi, nq_rej_memory, nq_rej_growth, nq_bias_same, nq_bias_down, nq_bias_up,
+                           newton_tol, rate_max_age, rate_first_safety, e_weight, honor_hmax, hmax_deep, hmax_scale, tail_frac, tail_factor, far_frac, far_factor, trts_rtol_factor,
+                           amp_ref, amp_post, nq_deadband_hi, nq_rej_memory, nq_rej_growth, nq_bias_same, nq_bias_down, nq_bias_up,
                            early_factor, early_frac};
     }
 };
@@ -188,11 +196,18 @@ struct Emitter {
     double *o;
     double min_y, scale;
     double deep_below;  // deep_frac x |first sample|
-    int clamped, deep;
-    __device__ inline void begin(double *o_, double min_y_, double scale_, double deep_frac)
+    double tail_below;  // tail_frac x |first sample|
+    double far_below;   // far_frac x |first sample|
+    double post_below;  // output level (absolute) below which the decay is low-injection
+    int clamped, deep, tail, far, post;
+    __device__ inline void begin(double *o_, double min_y_, double scale_, double deep_frac, double tail_frac, double far_frac,
+                                 double post_level)
     {
-        o = o_; min_y = min_y_; scale = scale_; clamped = 0; deep = 0;
+        o = o_; min_y = min_y_; scale = scale_; clamped = 0; deep = 0; tail = 0; far = 0; post = 0;
         deep_below = deep_frac;
+        tail_below = tail_frac;
+        far_below = far_frac;
+        post_below = post_level;
     }
     // total = dx-less grid sum; writer = this thread stores.  Every thread that calls sees the same v,
     // so `deep` is uniform among the callers.
@@ -200,6 +215,9 @@ struct Emitter {
     {
         double v = total * dx * scale;
         deep_below = deep_below * fabs(v);  // the first sample fixes the scale
+        tail_below = tail_below * fabs(v);
+        far_below = far_below * fabs(v);
+        post = !(fabs(v) >= post_below);
         clamped = v < min_y;
         if (clamped) v = min_y;
         if (writer) o[0] = v;
@@ -208,6 +226,9 @@ struct Emitter {
     {
         double v = total * dx * scale;
         deep |= !(fabs(v) >= deep_below);
+        tail |= !(fabs(v) >= tail_below);
+        far |= !(fabs(v) >= far_below);
+        post |= !(fabs(v) >= post_below);
         clamped |= v < min_y;
         if (clamped) v = min_y;
         if (writer) o[k] = v;
@@ -234,7 +255,16 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
     const double *ts = tsteps + ds.t_off;
     const real hmax = tune.honor_hmax ? (real)(ds.hmax * tune.hmax_scale) : big<real>();
     const ctl inv_S = (ctl)(1.0 / (double)((TRAPS ? 4 : 3) * L + 1));
-    bk.out_begin(out + ds.out_off, ds.min_y, (meas == MTRPL_MEAS_TRPL) ? 1e23 : 1e9, tune.hmax_deep);  // forward_solver.py:189,:197
+    const double out_scale = (meas == MTRPL_MEAS_TRPL) ? 1e23 : 1e9;  // forward_solver.py:189,:197
+    // output level of a film whose excess density is amp_post x p0 everywhere: ks dn (dn + p0 + n0) L (PL) or
+    // q (mu_n + mu_p) dn L (TRTS); below it the decay is low-injection (amp_post, DESIGN.md "error control")
+    double post_level = 0.0;
+    {
+        const double dn = tune.amp_post * ds.par[MTRPL_P_P0], n0_ = ds.par[MTRPL_P_N0], p0_ = ds.par[MTRPL_P_P0];
+        post_level = ((meas == MTRPL_MEAS_TRPL) ? ds.par[MTRPL_P_KS] * dn * (dn + p0_ + n0_)
+                                                : kQC * (ds.par[MTRPL_P_MU_N] + ds.par[MTRPL_P_MU_P]) * dn) * ds.thickness * out_scale;
+    }
+    bk.out_begin(out + ds.out_off, ds.min_y, out_scale, tune.hmax_deep, tune.tail_frac, tune.far_frac, post_level);
     const int lane64 = (int)(threadIdx.x & 63);
 
     // ---- initial condition, forward_solver.py:100-122 ----
@@ -287,6 +317,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
     // rtol_min -- a request below that is raised to it and reported as MTRPL_SOLVE_OK_TOL_CLAMPED.
     bool tol_clamped = false;
     real rtol, atol, atol_E;
+    double amp_mul_d = 1.0;
     {
         const double req = tune.rtol_scale * ds.rtol;
         const double base = fmin(req, tune.rtol_cap);
@@ -299,7 +330,12 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             // SRH with tauP >> tauN (p-type): the decay rate rises from 1/(tauN+tauP) at high injection to
             // 1/tauN at low injection, and a relative error made before that transition is amplified by the
             // ratio of the two rates (d ln(dN/N)/dt = -r'(N) N): tighten by that a-priori factor.
-            if (tune.amp_ref > 0.0) r_ /= fmax(1.0, (1.0 + ds.par[MTRPL_P_TAUP] / ds.par[MTRPL_P_TAUN]) / tune.amp_ref);
+            // (applied as a factor on the error norms of the steps taken while the decay is still high-injection:
+            // amp_mul below; here only its part that the floor allows)
+            if (tune.amp_ref > 0.0) {
+                const double amp = fmax(1.0, (1.0 + ds.par[MTRPL_P_TAUP] / ds.par[MTRPL_P_TAUN]) / tune.amp_ref);
+                amp_mul_d = fmin(amp, fmax(1.0, r_ / tune.rtol_floor));
+            }
             r_ = fmax(r_, tune.rtol_floor);
         } else {
             r_ = base;  // the caller asked for more than the policy would ever do
@@ -327,6 +363,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
     const ctl rtol_f = (ctl)rtol, rtol_E_f = (ctl)rtol_E, atol_f = (ctl)atol, atol_E_f = (ctl)atol_E;
     const real early_until = (nt > 1) ? (real)(tune.early_frac * ts[1]) : (real)0;
     const ctl early_mul = (ctl)(1.0 / fmax(tune.early_factor, 1.0));  // norms of an early step are scaled by this
+    const ctl tail_mul = (ctl)(1.0 / tune.tail_factor), far_mul = (ctl)(1.0 / tune.far_factor), amp_mul = (ctl)amp_mul_d;
     const ctl newton_tol = (tune.newton_tol > 0.0)
                                ? (ctl)tune.newton_tol
                                : (ctl)fmax(10.0 * 2.220446049250313e-16 / (double)rtol, fmin(0.03, sqrt((double)rtol)));
@@ -447,7 +484,12 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         const real c = h * el0;
         // steps that end before early_frac x the first sample time get early_factor x the local tolerance: the
         // norms of such a step are scaled instead of its weights
-        const ctl nscale = (tune.early_factor > 1.0 && t + h <= early_until) ? early_mul : 1.0f;
+        // ... and steps taken once the signal has fallen tail_frac (far_frac) below its first sample tail_factor x
+        // (far_factor x)
+        // ... and the steps of a tauP >> tauN solve amp x tighter while its decay is high-injection
+        const ctl nscale = ((tune.early_factor > 1.0 && t + h <= early_until) ? early_mul
+                                                                              : (bk.far() ? far_mul : (bk.tail() ? tail_mul : 1.0f))) *
+                           (bk.post() ? 1.0f : amp_mul);
         // error weights of this step, 1/(atol + rtol |y_predicted|), fp32
         float isc[V];
 #pragma unroll
