@@ -1,0 +1,105 @@
+"""
+make_team_cases.py -- converged-oracle fixtures for the multi-wave ("team") kernels, tests/test_gpu_team.py
+(missing 4): the kernels that serve nx > 128 and the traps model.
+
+  nx512     16 solves = the first 4 states of the seeded config-5 stream x (2000 nm, 311 nm) x (TRPL, TRTS)
+            (BASELINE.json configs[4]; metrotrpl_amd.workloads.config5), nx = 512
+  nx256     8 solves = the next 2 states x the same four, nx = 256
+  traps     8 draws of the config-2 stream with NON-NULL trap parameters (kC, Nt, tauE log-uniform), nx = 128,
+            thick and thin film alternating, TRPL (forward_solver.py:374-418)
+  mixed     the log-likelihood table of one TRPL + TRTS measurement pair at nx = 512 (sigma 1 / 10 as
+            Tests/test_eval_trial_move.py:321) from the oracle's eval_trial_move at tight tolerance
+
+Oracle: SciPy LSODA + gcc RHS at RTOL 1e-12 / ATOL 1e-17 (valid over the first four decades of a trace, like
+solve_converged.npz).  1001 samples over 2000 ns (nx512 / nx256), 501 over 1000 ns (traps).
+
+    python tests/golden/make_team_cases.py            (about 15 minutes on 8 cores)
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+from metrotrpl_amd import workloads as W  # noqa: E402
+
+IX, UN = W.indexes(), W.units()
+TNAMES = W.PARAM_NAMES + ["kC", "Nt", "tauE"]
+TUN = np.array(list(UN) + [((1e7) ** 3) / (1e9), ((1e-7) ** 3), 1.0])  # Tests/test_metropolis.py:282-289
+TIX = {n: i for i, n in enumerate(TNAMES)}
+C5 = W.config5(6)
+T_TRAPS = np.linspace(0, 1000, 501)
+
+
+def trap_cases():
+    rng = np.random.default_rng(W.SEED + 5)
+    c2 = W.config2(8)
+    states = np.zeros((8, len(TNAMES)))
+    states[:, :len(W.PARAM_NAMES)] = c2["states"]
+    states[:, TIX["kC"]] = 10 ** rng.uniform(-11, -9, 8)     # cm^3 s^-1
+    states[:, TIX["Nt"]] = 10 ** rng.uniform(14, 16, 8)      # cm^-3
+    states[:, TIX["tauE"]] = 10 ** rng.uniform(0.5, 3, 8)    # ns
+    thick = np.where(np.arange(8) % 2 == 0, 2000.0, 311.0)
+    return states, c2["iniPar"], thick
+
+
+def one(job):
+    from oracle import oracle as O
+    kind, k = job
+    if kind == "traps":
+        st, ini, th = trap_cases()
+        g = O.Grid(float(th[k]), 128, T_TRAPS, 4.0)
+        return O.solve(ini[k], g, st[k], TIX, units=TUN, model="traps", ini_mode="fluence", RTOL=1e-12, ATOL=1e-17)
+    nx = 512 if kind == "nx512" else 256
+    g = O.Grid(float(C5["thickness"][k]), nx, C5["tSteps"], C5["hmax"])
+    return O.solve(C5["iniPar"][k], g, C5["states"][k], IX, meas=C5["meas"][k], units=UN, ini_mode="fluence",
+                   RTOL=1e-12, ATOL=1e-17)
+
+
+def mixed_case():
+    """One chain, two measurements at nx = 512: (2000 nm, TRPL) and (311 nm, TRTS); the data are the oracle's own
+    traces of a NEIGHBOURING state (so the log-likelihood is finite and sensitive), 0.02 / 0.05 uncertainties."""
+    from oracle import oracle as O
+    t = C5["tSteps"][:201]  # 400 ns
+    k = 4  # the second state of the stream: both traces stay within 1.5 decades over the 400 ns window
+    state, other = C5["states"][k], C5["states"][k].copy()
+    other[IX["tauN"]] *= 1.15
+    other[IX["ks"]] *= 0.9
+    shared = {"_sim_info": {"lengths": [2000.0, 311.0], "nx": [512, 512], "meas_types": ["TRPL", "TRTS"], "num_meas": 2},
+              "_param_indexes": IX, "units": UN, "_init_params": np.array([C5["iniPar"][k], C5["iniPar"][k]]),
+              "_times": [t, t], "hmax": 4.0, "solver": ("solveivp",), "model": "std", "ini_mode": "fluence",
+              "rtol": 1e-10, "atol": 1e-14}
+    vals = []
+    for m, (th, meas) in enumerate(((2000.0, "TRPL"), (311.0, "TRTS"))):
+        g = O.Grid(th, 512, t, 4.0)
+        vals.append(np.log10(O.solve(shared["_init_params"][m], g, other, IX, meas=meas, units=UN, ini_mode="fluence",
+                                     RTOL=1e-10, ATOL=1e-14)))
+    shared["_vals"], shared["_uncs"] = vals, [np.full(t.shape, 0.02), np.full(t.shape, 0.05)]
+    T = np.array([1.0, 3.0, 30.0, 1000.0])
+    uniq = {"model_uncertainty": {"TRPL": 1.0, "TRTS": 10.0}, "_T": 1.0}
+    _, table = O.eval_trial_move(state, uniq, shared, temperatures=T)
+    return dict(mixed_state=state, mixed_t=t, mixed_vals=np.array(vals), mixed_uncs=np.array(shared["_uncs"]),
+                mixed_ini=shared["_init_params"], mixed_T=T, mixed_table=table, mixed_sigma=np.array([1.0, 10.0]))
+
+
+if __name__ == "__main__":
+    from multiprocessing import Pool
+    from oracle import oracle as O
+    O.build()
+    jobs = [("nx512", k) for k in range(16)] + [("nx256", k) for k in range(16, 24)] + [("traps", k) for k in range(8)]
+    with Pool(min(8, os.cpu_count() or 1)) as p:
+        res = p.map(one, jobs, chunksize=1)
+        mixed = p.apply(mixed_case)
+    st_t, ini_t, th_t = trap_cases()
+    out = dict(names=np.array(",".join(W.PARAM_NAMES)), units=UN, tSteps=C5["tSteps"],
+               nx512_states=C5["states"][:16], nx512_ini=C5["iniPar"][:16], nx512_thickness=C5["thickness"][:16],
+               nx512_meas=np.array(C5["meas"][:16]), nx512_sig=np.array(res[:16]),
+               nx256_states=C5["states"][16:24], nx256_ini=C5["iniPar"][16:24], nx256_thickness=C5["thickness"][16:24],
+               nx256_meas=np.array(C5["meas"][16:24]), nx256_sig=np.array(res[16:24]),
+               traps_names=np.array(",".join(TNAMES)), traps_units=TUN, traps_states=st_t, traps_ini=ini_t,
+               traps_thickness=th_t, traps_t=T_TRAPS, traps_sig=np.array(res[24:32]), **mixed)
+    np.savez_compressed(os.path.join(HERE, "team_cases.npz"), **out)
+    print("wrote team_cases.npz:", {k: np.shape(v) for k, v in out.items()})

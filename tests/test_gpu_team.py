@@ -159,3 +159,71 @@ def test_fp32_build_of_the_team_kernel(gold):
             ctx.set_option(k, v)
     sig, _ = _run(gold, "cfg5_thick_pl__tight")
     assert _relerr(sig, gold["cfg5_thick_pl__tight__sig"]) <= REL_TOL  # fp64 path untouched
+
+
+# ---- converged-oracle fixtures for the team kernels (tests/golden/make_team_cases.py) -----------------------
+@pytest.fixture(scope="module")
+def team():
+    return np.load(os.path.join(G, "team_cases.npz"))
+
+
+def _window_err(sig, ref):
+    return np.array([_relerr(sig[k], ref[k]) for k in range(len(ref))])
+
+
+@pytest.mark.parametrize("which,nx,n", [("nx512", 512, 16), ("nx256", 256, 8)])
+def test_team_kernels_on_converged_config5_traces(team, which, nx, n):
+    """nx = 512 (four waves per solve, blocks in LDS as fp32) and nx = 256 (two waves): thick and thin film, TRPL and
+    TRTS (BASELINE.json configs[4]), against converged oracle traces, 1e-6 over the four-decade window."""
+    from metrotrpl_amd import batch
+    idx = {k: i for i, k in enumerate(str(team["names"]).split(","))}
+    ref = team[which + "_sig"]
+    assert ref.shape == (n, 1001)
+    meas = [str(m) for m in team[which + "_meas"]]
+    assert set(meas) == {"TRPL", "TRTS"} and set(team[which + "_thickness"]) == {2000.0, 311.0}
+    sig, status, stats = batch.solve_batch(team[which + "_states"], idx, team["units"], team[which + "_ini"],
+                                           team[which + "_thickness"], nx, team["tSteps"], meas=meas, return_stats=True)
+    assert np.all(status == 0)
+    err = _window_err(sig, ref)
+    print(f"{which}: worst {err.max():.2e} (TRPL {err[::2].max():.2e}, TRTS {err[1::2].max():.2e}), steps "
+          f"{stats[:, 0].min()}..{stats[:, 0].max()}")
+    assert err.max() <= REL_TOL, err
+
+
+def test_traps_kernel_on_converged_traces_with_real_traps(team):
+    """a5 with NON-NULL trap parameters (kC, Nt, tauE drawn log-uniformly): 8 converged oracle traces, thick and
+    thin film, through TeamBackend<.., TRAPS=true> (forward_solver.py:374-418)."""
+    from metrotrpl_amd import batch
+    names = str(team["traps_names"]).split(",")
+    idx = {k: i for i, k in enumerate(names)}
+    st = team["traps_states"]
+    assert np.all(st[:, idx["kC"]] > 0) and np.all(st[:, idx["Nt"]] > 0)
+    sig, status, stats = batch.solve_batch(st, idx, team["traps_units"], team["traps_ini"], team["traps_thickness"], 128,
+                                           team["traps_t"], model="traps", return_stats=True)
+    assert np.all(status == 0)
+    err = _window_err(sig, team["traps_sig"])
+    print(f"traps: worst {err.max():.2e}, steps {stats[:, 0].min()}..{stats[:, 0].max()}")
+    assert err.max() <= REL_TOL, err
+    # the traps do something: the same states with the traps switched off give another trace
+    off = st.copy()
+    off[:, idx["kC"]] = 0.0
+    sig0 = batch.solve_batch(off, idx, team["traps_units"], team["traps_ini"], team["traps_thickness"], 128, team["traps_t"],
+                             model="traps")
+    assert np.max(np.abs(sig0[:, 100] / sig[:, 100] - 1)) > 1e-3
+
+
+def test_mixed_trpl_trts_likelihood_at_nx512(team):
+    """Config 5's mixed TRPL + TRTS likelihood (model uncertainties 1 / 10, Tests/test_eval_trial_move.py:321) through
+    the LikelihoodEngine at nx = 512 against the oracle's eval_trial_move at tight tolerance, every temperature."""
+    from metrotrpl_amd.likelihood import LikelihoodEngine
+    from metrotrpl_amd import workloads as W
+    t = team["mixed_t"]
+    eng = LikelihoodEngine(W.indexes(), W.units(), [2000.0, 311.0], 512, ["TRPL", "TRTS"], [t, t], list(team["mixed_vals"]),
+                           list(team["mixed_uncs"]), {"TRPL": float(team["mixed_sigma"][0]), "TRTS": float(team["mixed_sigma"][1])},
+                           team["mixed_ini"], ini_mode="fluence")
+    table = eng.eval(team["mixed_state"][None, :], team["mixed_T"])[0]
+    ref = team["mixed_table"]
+    assert ref.shape == table.shape == (2, 4) and np.all(np.isfinite(ref)) and np.all(ref < 0)
+    # atol as in test_gpu_likelihood: n (d log10)^2 with d log10 ~ 4e-8 (1e-7 relative on the signal); the TRTS row is a
+    # near-perfect fit (ll ~ 1e-4) and sits next to it
+    np.testing.assert_allclose(table, ref, rtol=1e-6, atol=1e-9 * np.max(np.abs(ref)) + 1e-10)
