@@ -13,16 +13,18 @@ synthetic batch per GPU, nx=128, thickness 2000 nm, 1001 output times over
 
 The K timed steps are independent batches, so they are issued the way a caller with
 more than one batch to do issues them: round-robin on three HIP streams, on the
-two-solves-per-SIMD form of the wave kernel, every batch AS DRAWN (no re-ordering of
-its solves) -- a solve holds its SIMD slot for its whole duration and durations spread
-1:1.5, so the slots the short solves of one launch free go to the next launch.  Measured
-in the same run and reported beside it:
+two-solves-per-SIMD form of the wave kernel, every batch handed over AS DRAWN -- a solve
+holds its SIMD slot for its whole duration and durations spread 1:1.5, so the slots the
+short solves of one launch free go to the next launch.  Inside a launch the library issues
+the solves by descending EXPECTED cost, a model of the descriptors alone (csrc/launch_order.hpp):
+nothing is measured beforehand.  Measured in the same run and reported beside it:
+  as_given                 the timed region with that ordering switched off (order_min_batch = 0)
   single_stream            the same K steps back to back on ONE stream, one solve per
                            SIMD: every launch alone on the device (latency, the kernel's own speed)
-  sorted_by_measured_cost  the three-stream region again with each batch's solves issued
-                           longest first, the order measured on the identical batch in a
-                           warm-up launch -- knowledge a first-time caller does not have, so
-                           it is an upper bound of what ordering can buy, not the headline
+  sorted_by_measured_cost  ... and with each batch's solves issued longest first by the cost
+                           MEASURED on the identical batch in a warm-up launch -- knowledge a
+                           first-time caller does not have: an upper bound of what ordering can
+                           buy, not the headline
   fp64_linear_algebra      single_stream on kernel_variant 2 (fp64 blocks, fp64 re-solve)
   pt                       BASELINE's second metric: MCMC proposals/s of the config-3 (64 chains)
                            and config-4-on-one-GPU (512 chains) parallel-tempering ensembles
@@ -347,8 +349,16 @@ def main():
         single = (dt, kern_ms, ok)
     status = d_status.cpu().numpy()
     stats = d_stats.cpu().numpy().reshape(B, 8)
-    # ---- (3) the same region with each batch's solves longest first (order measured on the identical batch) ----
+    # ---- (3) the same region as given (no ordering at all), and with each batch's solves longest first by the
+    #          cost measured on the identical batch (the library's own ordering off in both) ----
+    given_leg = None
     if not a.quick and S > 1 and not a.sort_by_cost:
+        order_min = ctx.get_option("order_min_batch")
+        ctx.set_option("order_min_batch", 0)
+        for k in range(S):
+            step(k)
+        torch.cuda.synchronize()
+        given_leg = timed(S)
         order = np.argsort(-stats_drawn[:, 7], kind="stable")
         cur["descs"] = torch.from_numpy(descs[order].view(np.uint8).reshape(-1)).to(dev)
         for k in range(S):
@@ -356,6 +366,7 @@ def main():
         torch.cuda.synchronize()
         sorted_leg = timed(S)
         cur["descs"] = d_descs_drawn
+        ctx.set_option("order_min_batch", order_min)
 
     # measured HBM stream rate of this device (read + write of a 1 GiB buffer), next to the nominal peak
     copy_gbs = None
@@ -412,11 +423,15 @@ def main():
                        **({"options": a.opt} if a.opt else {}),
                        "streams": S, "solves_per_simd": 2 if (S > 1 and not user_variant) else "as set by --opt" if user_variant
                        else 1, "issue_order": "longest first (measured in a warm-up launch of the identical batch)"
-                       if a.sort_by_cost else "as drawn",
+                       if a.sort_by_cost else "batches handed over as drawn; inside a launch the library issues the solves by "
+                       "descending expected cost, a model of the descriptors alone (csrc/launch_order.hpp)",
                        "as_drawn": not a.sort_by_cost},
             "single_stream": None if single is None else {
                 **region(*single), "note": "the same K steps back to back on one HIP stream, as drawn, one solve per SIMD "
                                            "(every launch alone on the device), measured in this run"},
+            "as_given": None if given_leg is None else {
+                **region(*given_leg), "note": "the timed region with the library's launch ordering off: solves issued in the "
+                                              "order of the descriptor array"},
             "sorted_by_measured_cost": None if sorted_leg is None else {
                 **region(*sorted_leg), "note": "the timed region again with each batch's solves issued longest first, the "
                                                "order measured on the identical batch in a warm-up launch: an upper bound of "

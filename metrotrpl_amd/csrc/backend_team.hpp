@@ -406,17 +406,17 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_team(const mtrpl_solve_de
                                                              const double *__restrict__ tsteps,
                                                              double *__restrict__ out, int32_t *__restrict__ status,
                                                              int32_t *__restrict__ stats, int64_t B, SolveTuning tune,
-                                                             void *__restrict__ gblk)
+                                                             void *__restrict__ gblk, const int32_t *__restrict__ perm)
 {
     using BK = TeamBackend<T_, W, TRAPS, GBLK, BF32>;
     using row_t = typename BK::row_t;
-    const int64_t sidx = blockIdx.x;
     const unsigned long long clk0_ = __builtin_amdgcn_s_memtime();
-    if (sidx >= B) return;
+    if ((int64_t)blockIdx.x >= B) return;
+    const int64_t sidx = perm ? perm[blockIdx.x] : blockIdx.x;  // launch_order.hpp
     __shared__ row_t xbuf_lds[BK::kXbufRows];
     __shared__ T_ rbuf_lds[BK::kRbufVals];
     __shared__ row_t blk_lds[GBLK ? 1 : BK::kBlkRows];
-    row_t *blkp = GBLK ? (static_cast<row_t *>(gblk) + (size_t)sidx * BK::kBlkRows) : blk_lds;
+    row_t *blkp = GBLK ? (static_cast<row_t *>(gblk) + (size_t)blockIdx.x * BK::kBlkRows) : blk_lds;
     BK bk(threadIdx.x, xbuf_lds, rbuf_lds, blkp);
     integrate(bk, descs[sidx], ini, tsteps, out, status, stats, sidx, tune, clk0_);
 }

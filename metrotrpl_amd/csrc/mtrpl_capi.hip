@@ -14,6 +14,7 @@
 #include "irf_kernels.hpp"
 #include "backend_wave.hpp"
 #include "backend_team.hpp"
+#include "launch_order.hpp"
 
 using namespace mtrpl;
 
@@ -26,6 +27,7 @@ struct Slab {
     size_t bytes = 0;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
+    unsigned long long taken_in = 0;  // the API call that handed it out last (one call may take two slabs)
 };
 }  // namespace
 
@@ -47,6 +49,10 @@ struct mtrpl_ctx {
     int kernel_variant = 0;  // see include/metrotrpl_amd.h
     int precision = 64;      // 64: fp64 (the product); 32: the fp32 build of the team kernel (precision sweep only)
     size_t like_lds_attr = 64 * 1024;  // dynamic-LDS limit the likelihood kernel has been raised to
+    unsigned long long call_id = 0;
+    bool order_lds_raised = false;
+    int order_min_batch = 256;  // launches of at least this many solves issue them by descending expected cost
+                                // (launch_order.hpp; 0: as given).  Only the issue order: results do not depend on it
     int two_per_simd_min_batch = 1025;  // kernel_variant 0: launches of at least this many std / nx <= 128 solves use
                                         // the two-solves-per-SIMD build of the wave kernel (more than one solve per
                                         // SIMD anyway), smaller ones the one-per-SIMD build: same results
@@ -284,6 +290,7 @@ int take_slab(mtrpl_ctx *ctx, size_t need, hipStream_t s, Slab **out)
 {
     Slab *pick = nullptr, *small = nullptr;
     for (Slab &sl : ctx->slabs) {
+        if (sl.taken_in == ctx->call_id) continue;  // handed out earlier in this very call
         bool free_ = sl.stream == s;
         if (!free_) {
             const hipError_t q = hipEventQuery(sl.done);
@@ -322,6 +329,7 @@ int take_slab(mtrpl_ctx *ctx, size_t need, hipStream_t s, Slab **out)
         }
     }
     pick->stream = s;
+    pick->taken_in = ctx->call_id;
     *out = pick;
     return MTRPL_OK;
 }
@@ -337,22 +345,22 @@ int seal_slab(mtrpl_ctx *ctx, Slab *sl, hipStream_t s, bool launched)
 template <class T, int W, bool TRAPS, bool GBLK, bool BF32 = false>
 void launch_team(hipStream_t s, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
                  const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats,
-                 const SolveTuning &tune, void *gblk)
+                 const SolveTuning &tune, void *gblk, const int32_t *perm)
 {
     hipLaunchKernelGGL((solve_kernel_team<T, W, TRAPS, GBLK, BF32>), dim3((unsigned)B), dim3(64 * W), 0, s, d_descs, d_ini,
-                       d_tsteps, d_out, d_status, d_stats, B, tune, gblk);
+                       d_tsteps, d_out, d_status, d_stats, B, tune, gblk, perm);
 }
 template <class T>
 int launch_team_any(mtrpl_ctx *ctx, hipStream_t s, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
                     const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats, int32_t max_nx,
-                    bool traps)
+                    bool traps, const int32_t *perm)
 {
     // fp64 solves store their elimination blocks as fp32 (half the LDS: twice the workgroups per CU at W = 2)
     constexpr bool kF32 = sizeof(T) == 8;
 #define MTRPL_TEAM(W_, G_, P_)                                                                                       \
     do {                                                                                                             \
-        if (traps) launch_team<T, W_, true, G_, kF32>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, P_); \
-        else launch_team<T, W_, false, G_, kF32>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, P_);      \
+        if (traps) launch_team<T, W_, true, G_, kF32>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, P_, perm); \
+        else launch_team<T, W_, false, G_, kF32>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, P_, perm);      \
     } while (0)
     if (max_nx <= 128) MTRPL_TEAM(1, false, nullptr);
     else if (max_nx <= 256) MTRPL_TEAM(2, false, nullptr);
@@ -377,6 +385,30 @@ int launch_team_any(mtrpl_ctx *ctx, hipStream_t s, int64_t B, const mtrpl_solve_
         }
     }
 #undef MTRPL_TEAM
+    return MTRPL_OK;
+}
+
+// the issue order of a launch (launch_order.hpp): a permutation in a slab of its own, sorted on the device behind
+// whatever the stream holds; nullptr = as given
+int make_order(mtrpl_ctx *ctx, hipStream_t s, int64_t B, const mtrpl_solve_desc *d_descs, const int32_t **perm, Slab **slab)
+{
+    *perm = nullptr;
+    *slab = nullptr;
+    if (ctx->order_min_batch <= 0 || B < ctx->order_min_batch || B > kOrderMax) return MTRPL_OK;
+    int n_pad = 1;
+    while (n_pad < B) n_pad <<= 1;
+    Slab *sl = nullptr;
+    const int rc = take_slab(ctx, sizeof(int32_t) * (size_t)B, s, &sl);
+    if (rc != MTRPL_OK) return rc;
+    const size_t lds = sizeof(unsigned long long) * (size_t)n_pad;
+    if (lds > 64 * 1024 && !ctx->order_lds_raised) {
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&order_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned long long) * kOrderMax)));
+        ctx->order_lds_raised = true;
+    }
+    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), lds, s, d_descs, (int)B, n_pad, static_cast<int32_t *>(sl->p));
+    *perm = static_cast<const int32_t *>(sl->p);
+    *slab = sl;
     return MTRPL_OK;
 }
 
@@ -475,6 +507,8 @@ int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value)
         // removed in round 2 (the Jacobian is always refreshed at a refactorisation): accepted and ignored
     } else if (k == "two_per_simd_min_batch") {
         ctx->two_per_simd_min_batch = (int)value;
+    } else if (k == "order_min_batch") {
+        ctx->order_min_batch = (int)value;
     } else if (k == "precision") {
         if (value != 32 && value != 64) return bad(ctx, MTRPL_ERR_BAD_ARG, "precision must be 32 or 64");
         ctx->precision = (int)value;
@@ -494,6 +528,7 @@ int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value)
         if (k == o.key) { *value = ctx->tune.*(o.m); return MTRPL_OK; }
     if (k == "kernel_variant") *value = ctx->kernel_variant;
     else if (k == "two_per_simd_min_batch") *value = ctx->two_per_simd_min_batch;
+    else if (k == "order_min_batch") *value = ctx->order_min_batch;
     else if (k == "precision") *value = ctx->precision;
     else return MTRPL_ERR_BAD_ARG;
     return MTRPL_OK;
@@ -509,11 +544,23 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
     if (max_nx < 2 || max_nx > 512) return bad(ctx, MTRPL_ERR_UNSUPPORTED, "nx > 512 not supported by this build");
     if (model != MTRPL_MODEL_STD && model != MTRPL_MODEL_TRAPS) return bad(ctx, MTRPL_ERR_BAD_ARG, "Invalid model");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->call_id++;
     hipStream_t s = (hipStream_t)stream;  // exactly the caller's stream (NULL = the default stream)
     const bool traps = model == MTRPL_MODEL_TRAPS;
+    const int32_t *perm = nullptr;
+    Slab *order_slab = nullptr;
+    {
+        const int rc = make_order(ctx, s, B, d_descs, &perm, &order_slab);
+        if (rc != MTRPL_OK) return rc;
+    }
+    // the permutation's slab is free again once the solve kernel behind it has run
+    struct SealOrder {
+        mtrpl_ctx *c; Slab *sl; hipStream_t s;
+        ~SealOrder() { if (sl) (void)hipEventRecord(sl->done, s); }
+    } seal_order{ctx, order_slab, s};
     if (ctx->precision == 32) {
         if (traps) return bad(ctx, MTRPL_ERR_UNSUPPORTED, "the fp32 build covers the std model only");
-        const int rc = launch_team_any<float>(ctx, s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, max_nx, false);
+        const int rc = launch_team_any<float>(ctx, s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, max_nx, false, perm);
         if (rc != MTRPL_OK) return rc;
         HIP_TRY(ctx, hipGetLastError());
         return MTRPL_OK;
@@ -532,12 +579,12 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
 #define MTRPL_WAVE(KERNEL)                                                                                            \
     do {                                                                                                              \
         if (ct) hipLaunchKernelGGL(KERNEL<true>, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,  \
-                                   d_status, d_stats, B, ctx->tune);                                                  \
+                                   d_status, d_stats, B, ctx->tune, perm);                                            \
         else hipLaunchKernelGGL(KERNEL<false>, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,    \
-                                d_status, d_stats, B, ctx->tune);                                                     \
+                                d_status, d_stats, B, ctx->tune, perm);                                               \
     } while (0)
     if (traps || max_nx > 128 || variant == 1) {
-        const int rc = launch_team_any<double>(ctx, s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, max_nx, traps);
+        const int rc = launch_team_any<double>(ctx, s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, max_nx, traps, perm);
         if (rc != MTRPL_OK) return rc;
     } else if (variant == 3) {
         MTRPL_WAVE(solve_kernel_wave2);
