@@ -705,6 +705,32 @@ int mtrpl_newton_probe(mtrpl_ctx *ctx, int64_t B, int32_t nx, const double *par,
     return MTRPL_OK;
 }
 
+int mtrpl_launch_order(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *descs, int32_t *perm)
+{
+    if (!ctx) return MTRPL_ERR_BAD_ARG;
+    if (B <= 0) return MTRPL_OK;
+    if (!descs || !perm) return bad(ctx, MTRPL_ERR_BAD_ARG, "null pointer");
+    if (B > kOrderMax) return bad(ctx, MTRPL_ERR_UNSUPPORTED, "launches of more than 16384 solves are issued as given");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf dd(ctx, 0);
+    HIP_TRY(ctx, dd.alloc(sizeof(mtrpl_solve_desc) * B));
+    hipStream_t s = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(dd.p, descs, sizeof(mtrpl_solve_desc) * B, hipMemcpyHostToDevice, s));
+    const int saved = ctx->order_min_batch;
+    ctx->order_min_batch = 1;
+    ctx->call_id++;
+    const int32_t *d_perm = nullptr;
+    Slab *sl = nullptr;
+    const int rc = make_order(ctx, s, B, dd.as<mtrpl_solve_desc>(), &d_perm, &sl);
+    ctx->order_min_batch = saved;
+    if (rc != MTRPL_OK) return rc;
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(perm, d_perm, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipEventRecord(sl->done, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return MTRPL_OK;
+}
+
 int mtrpl_reduce_probe(mtrpl_ctx *ctx, int64_t B, const float *in, float *out)
 {
     if (!ctx) return MTRPL_ERR_BAD_ARG;

@@ -134,3 +134,35 @@ def test_odd_and_tiny_grids_against_the_oracle():
             m = ref >= 1e-3 * ref[0]
             err = np.max(np.abs(sig[m] - ref[m]) / ref[m])
             assert err < 1e-6, (nx, thick, meas, err)
+
+
+def test_launch_order_is_a_permutation_by_cost_and_changes_no_result():
+    """csrc/launch_order.hpp: a launch issues its solves by descending expected cost (a model of the descriptors alone,
+    sorted on the device).  The order is a permutation, it puts the solves that turn out expensive first (rank
+    correlation with the measured step counts), and no result depends on it -- bit for bit."""
+    import ctypes as C
+    from scipy.stats import spearmanr
+    from metrotrpl_amd import batch, workloads as W
+    L, ctx = _ctx()
+    B = 700  # not a power of two
+    c = W.config2(B)
+    d, ini = batch.build_batch(c["states"], W.indexes(), W.units(), c["iniPar"], c["thickness"], c["nx"], len(c["tSteps"]))
+    perm = np.full(B, -1, dtype=np.int32)
+    ctx.check(L.lib().mtrpl_launch_order(ctx.handle, B, d.ctypes.data_as(C.c_void_p), L.iptr(perm)))
+    assert sorted(perm.tolist()) == list(range(B))
+    assert ctx.get_option("order_min_batch") == 256
+    sig, status, stats = batch.solve_batch(c["states"], W.indexes(), W.units(), c["iniPar"], c["thickness"], c["nx"],
+                                           c["tSteps"], return_stats=True)
+    position = np.empty(B)
+    position[perm] = np.arange(B)
+    rho = spearmanr(-position, stats[:, 0]).correlation
+    print(f"rank correlation of the issue order with the measured step counts: {rho:.2f}")
+    assert rho > 0.7
+    ctx.set_option("order_min_batch", 0)
+    try:
+        sig0, status0, stats0 = batch.solve_batch(c["states"], W.indexes(), W.units(), c["iniPar"], c["thickness"], c["nx"],
+                                                  c["tSteps"], return_stats=True)
+    finally:
+        ctx.set_option("order_min_batch", 256)
+    np.testing.assert_array_equal(sig, sig0)
+    np.testing.assert_array_equal(stats[:, :7], stats0[:, :7])
