@@ -28,36 +28,27 @@ __device__ inline float cost_model(const mtrpl_solve_desc &d)
     return (c == c) ? c : 0.0f;
 }
 
-// perm[0..B) = solve indices by descending expected cost.  ONE workgroup: bitonic sort of (key, index) pairs in LDS,
-// n_pad = power of two >= B (<= kOrderMax).
+// perm[0..B) = solve indices by descending expected cost, in two passes of independent ONE-WAVE workgroups: the keys,
+// then the rank of every key among all of them (ties broken by index: a permutation).  One-wave workgroups on
+// purpose: with launches of the two-solves-per-SIMD kernel in flight every register file of the device is full, a
+// new wave can start only where a solve has just finished, and a 1024-thread sorting workgroup would wait for
+// sixteen such slots on ONE compute unit (measured: 0.44 ms on average in front of every launch).
 constexpr int kOrderMax = 16384;
-__global__ __launch_bounds__(1024) void order_kernel(const mtrpl_solve_desc *__restrict__ descs, int B, int n_pad,
-                                                     int32_t *__restrict__ perm)
+__global__ __launch_bounds__(64) void cost_key_kernel(const mtrpl_solve_desc *__restrict__ descs, int B, float *__restrict__ keys)
 {
-    extern __shared__ unsigned long long kv[];  // (sortable key << 32) | index
-    for (int i = threadIdx.x; i < n_pad; i += blockDim.x) {
-        unsigned key = 0u;  // padding sorts last
-        if (i < B) {
-            const unsigned u = __float_as_uint(cost_model(descs[i]));
-            key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // order-preserving map of float to unsigned
-            key = key ? key : 1u;
-        }
-        kv[i] = ((unsigned long long)key << 32) | (unsigned)i;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < B) keys[i] = cost_model(descs[i]);
+}
+__global__ __launch_bounds__(64) void cost_rank_kernel(const float *__restrict__ keys, int B, int32_t *__restrict__ perm)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const float mine = (i < B) ? keys[i] : 0.0f;
+    int rank = 0;
+    for (int j = 0; j < B; ++j) {  // keys[j]: a wave-uniform (scalar) load
+        const float kj = keys[j];
+        rank += (kj > mine || (kj == mine && j < i)) ? 1 : 0;
     }
-    __syncthreads();
-    for (int k = 2; k <= n_pad; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n_pad; i += blockDim.x) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const unsigned long long a = kv[i], b = kv[l];
-                    const bool desc = (i & k) == 0;  // descending blocks first: the final order is descending
-                    if (desc ? (a < b) : (a > b)) { kv[i] = b; kv[l] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    for (int i = threadIdx.x; i < B; i += blockDim.x) perm[i] = (int32_t)(kv[i] & 0xffffffffu);
+    if (i < B) perm[rank] = i;
 }
 
 }  // namespace mtrpl

@@ -50,7 +50,6 @@ struct mtrpl_ctx {
     int precision = 64;      // 64: fp64 (the product); 32: the fp32 build of the team kernel (precision sweep only)
     size_t like_lds_attr = 64 * 1024;  // dynamic-LDS limit the likelihood kernel has been raised to
     unsigned long long call_id = 0;
-    bool order_lds_raised = false;
     int order_min_batch = 256;  // launches of at least this many solves issue them by descending expected cost
                                 // (launch_order.hpp; 0: as given).  Only the issue order: results do not depend on it
     int two_per_simd_min_batch = 1025;  // kernel_variant 0: launches of at least this many std / nx <= 128 solves use
@@ -395,18 +394,14 @@ int make_order(mtrpl_ctx *ctx, hipStream_t s, int64_t B, const mtrpl_solve_desc 
     *perm = nullptr;
     *slab = nullptr;
     if (ctx->order_min_batch <= 0 || B < ctx->order_min_batch || B > kOrderMax) return MTRPL_OK;
-    int n_pad = 1;
-    while (n_pad < B) n_pad <<= 1;
     Slab *sl = nullptr;
-    const int rc = take_slab(ctx, sizeof(int32_t) * (size_t)B, s, &sl);
+    const int rc = take_slab(ctx, (sizeof(int32_t) + sizeof(float)) * (size_t)B, s, &sl);
     if (rc != MTRPL_OK) return rc;
-    const size_t lds = sizeof(unsigned long long) * (size_t)n_pad;
-    if (lds > 64 * 1024 && !ctx->order_lds_raised) {
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&order_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned long long) * kOrderMax)));
-        ctx->order_lds_raised = true;
-    }
-    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), lds, s, d_descs, (int)B, n_pad, static_cast<int32_t *>(sl->p));
+    int32_t *d_perm = static_cast<int32_t *>(sl->p);
+    float *d_keys = reinterpret_cast<float *>(d_perm + B);
+    const unsigned nwg = (unsigned)((B + 63) / 64);
+    hipLaunchKernelGGL(cost_key_kernel, dim3(nwg), dim3(64), 0, s, d_descs, (int)B, d_keys);
+    hipLaunchKernelGGL(cost_rank_kernel, dim3(nwg), dim3(64), 0, s, d_keys, (int)B, d_perm);
     *perm = static_cast<const int32_t *>(sl->p);
     *slab = sl;
     return MTRPL_OK;
