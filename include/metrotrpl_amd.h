@@ -112,14 +112,20 @@ const char *mtrpl_version(void);
 /* Integrator options.  Unknown key -> MTRPL_ERR_BAD_ARG.
  *   rtol_scale, rtol_cap              internal rtol = min(rtol_scale * desc.rtol, rtol_cap) ...
  *   trts_rtol_factor                  ... x this for TRTS solves ...
- *   amp_ref                           ... / max(1, (1 + tauP/tauN) / amp_ref)   (0 = off) ...
+ *   amp_ref, amp_post                 ... / max(1, (1 + tauP/tauN) / amp_ref) (0 = off; default 10) while the emitted signal
+ *                                     is above amp_post x its first sample (default 0.03: until the high- to low-injection
+ *                                     transition is behind the solve) ...
+ *   tail_frac, tail_factor            ... x tail_factor (0.4) once an emitted sample has fallen below tail_frac (1e-4) x the
+ *                                     first one, where the signal is a small difference of the state ...
+ *   far_frac, far_factor              ... x far_factor (3) instead below far_frac (1e-9): nothing measured reaches there ...
  *   rtol_floor                        ... these two policy factors never take it below rtol_floor;
  *   rtol_min                          a caller's own RTOL does go below rtol_floor, down to rtol_min
  *                                     (then MTRPL_SOLVE_OK_TOL_CLAMPED)
  *   rtol_force                        > 0: internal rtol = exactly this for every solve (tolerance sweeps)
  *   atol_rel                          absolute tolerance of the field components = rtol_int * atol_rel * max(N0, P0)
  *   atol_rel_np                       ... of the densities = min(rtol_int * atol_rel_np * max(N0, P0), desc.atol):
- *                                     1e-8 resolves a trace over 8 decades of decay (1e-4: the first 4, 6 % fewer steps)
+ *                                     default 1e-9 resolves a trace over 8 decades of decay inside the 1e-6 gate
+ *                                     (1e-4: the first 4, 6 % fewer steps)
  *   e_weight                          relative error weight of the field components (x rtol_int), TRPL solves only
  *   newton_tol, rate_max_age, rate_first_safety   simplified-Newton convergence control
  *   nq_deadband_hi                    a proposed step factor in [0.9, this) keeps the step and the factors (1.2)
@@ -128,6 +134,7 @@ const char *mtrpl_version(void);
  *   early_factor, early_frac          local tolerance x early_factor for steps that end before
  *                                     early_frac * (first requested sample time)
  *   honor_hmax                        1: desc.hmax is the maximum step (the reference's max_step) ...
+ *   hmax_scale                        ... x hmax_scale (default 1) ...
  *   hmax_deep                         ... while there is a signal: once an emitted sample has fallen below hmax_deep x
  *                                     the first sample (default 1e-11: the state sits at equilibrium to rounding) the
  *                                     error test alone sets the step for the rest of the solve (the flag latches and is
@@ -148,9 +155,8 @@ const char *mtrpl_version(void);
  *                                     smaller launches are in flight on different streams); a solve gives the same
  *                                     result on either build.  2: the wave kernel with fp64 blocks and an fp64
  *                                     re-solve (the exact linear algebra; agrees with the default inside the
- *                                     accuracy gate, not bitwise); 4 / 5 wave-pair kernel (two wavefronts per solve,
- *                                     blocks in registers / in LDS); 1 team kernel (the one traps and nx > 128 use);
- *                                     pair_max_batch: launches of at most this many solves use 4 (default 0)
+ *                                     accuracy gate, not bitwise); 1 team kernel (the one traps and nx > 128 use).
+ *                                     (4 / 5, round 2's wave-pair kernels, and pair_max_batch are gone: -> MTRPL_ERR_BAD_ARG)
  *   precision                         64 (product) | 32 (fp32 instantiation of the team kernel: precision sweep only) */
 int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value);
 int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value);

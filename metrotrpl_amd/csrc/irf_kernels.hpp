@@ -660,7 +660,7 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
                 const int j = u / kLadderSplit, r = u - j * kLadderSplit;
                 const double sT = sg2 * temps[j];
                 double tot = 0.0;
-                for (int i = r; i < n_c; i += kLadderSplit) tot += sol[i] * frcp(sT + su2[i]);  // frcp: ~1 ulp, no div ladder
+                for (int i = r; i < n_c; i += kLadderSplit) tot += sol[i] * frcp1(sT + su2[i]);  // hardware seed + one Newton step: 1e-16, no div ladder
                 parts[u] = tot;
             }
             __syncthreads();
@@ -675,7 +675,7 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
             for (int j = tid; j < nT; j += kLikeBlock) {
                 const double sT = sg2 * temps[j];
                 double tot = 0.0;
-                for (int i = 0; i < n_c; ++i) tot += sol[i] * frcp(sT + su2[i]);
+                for (int i = 0; i < n_c; ++i) tot += sol[i] * frcp1(sT + su2[i]);
                 tot = -tot;
                 if (failed || tot != tot) tot = -__builtin_inf();
                 ll[sidx * nT + j] = tot;

@@ -4,6 +4,12 @@
 T=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out
+# ---- counters of the two builds of the wave kernel (each group in its own pass) ----
+tools/pmc.sh $T > $O/${T}_pmc.log 2>&1
+# the bench line quotes VALU instructions / busy cycles / HBM bytes per solve from the committed summaries: put this
+# build's in place first (tools/collect_profiles.sh makes the same copy in the repository)
+cp $O/hbm_traffic_${T}_wave1.json profiles/hbm_traffic.json
+cp $O/hbm_traffic_${T}_wave2.json profiles/hbm_traffic_wave2.json
 # ---- the contract line (all legs: single stream, as given, sorted, fp64 linear algebra, PT) ----
 timeout -k 10 500 python bench.py --steps 30 --warmup 3 > $O/${T}_bench_config2.json 2> $O/${T}_bench.err
 # ---- kernel statistics of the timed kind of launch, and of one launch at a time ----
@@ -13,8 +19,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -- $BENCH > $
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${T}s1 -- $BENCH1 > $O/prof_${T}s1.log 2>&1
 cp $O/prof_$T/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_config2.csv
 cp $O/prof_${T}s1/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_config2_one_stream.csv
-# ---- counters of the two builds of the wave kernel (each group in its own pass) ----
-tools/pmc.sh $T > $O/${T}_pmc.log 2>&1
 # ---- config 5 (nx = 512): contract line, kernel statistics, counters of the team kernel ----
 timeout -k 10 300 python bench.py --workload config5 --steps 10 --warmup 2 > $O/${T}_bench_config5.json 2>> $O/${T}_bench.err
 C5="python3 bench.py --workload config5 --steps 4 --warmup 1"

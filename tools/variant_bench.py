@@ -1,6 +1,6 @@
 """Compare the solver backends on the config-2 workload: launch time at several batch sizes (HIP events),
 integrator step counts, per-solve residency, and agreement of the outputs with the default backend.
-usage: python tools/variant_bench.py [--variants 2,4,5] [--batches 1024,384,64] [--reps 5]"""
+usage: python tools/variant_bench.py [--variants 6,3,2] [--batches 1024,384,64] [--reps 5]"""
 import argparse
 import json
 import os
@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="2,4,5")
+    ap.add_argument("--variants", default="6,3,2")
     ap.add_argument("--batches", default="1024,512,384,64")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--nx", type=int, default=128)
