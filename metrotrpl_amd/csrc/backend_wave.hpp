@@ -22,7 +22,8 @@
 namespace mtrpl {
 
 constexpr int kFactorLdsBytes = 17 * 2 * 64 * 16;  // 34816 B per wave
-constexpr int kFactorLdsBytesF32 = 17 * 64 * 16;     // 17408 B per wave with blocks stored as 4 floats
+constexpr int kFactorLdsBytesF32 = 20 * 64 * 16;     // 20480 B per wave with blocks stored as 4 floats (17 + Bfin + 2 rows of eco):
+                                                     // 8 waves per CU fill the 160 KB exactly
 
 // F32BLK: the elimination blocks are STORED rounded to fp32 (one 16-byte row per block and lane) and the
 // re-solve exchanges and multiplies in packed fp32 (apply_f32); factorisation, residual, state and the running
@@ -48,7 +49,8 @@ struct WaveBackendT {
     // in this wave's LDS slab: [17 blocks][2 halves][64 lanes] x 16 B, i.e. every access is a
     // conflict-free ds_read/write_b128 (lane stride 16 B).
     void *lds;
-    enum { BINV_E = 0, BIA_E, BIC_E, CR_AL, CR_GA, PAL0, PGA0 = PAL0 + 6, NBLK = PGA0 + 6 };
+    enum { BINV_E = 0, BIA_E, BIC_E, CR_AL, CR_GA, PAL0, PGA0 = PAL0 + 6, NBLK = PGA0 + 6,
+           BFIN = NBLK, ECO0, ECO1 };  // fp32-stored blocks only: the last diagonal inverse and the field back-substitution rows
 
     int lds_off;  // lane * 16: byte offset of this lane's 16-byte row inside a block row
     __device__ inline WaveBackendT(int lane_, void *lds_) : lane(lane_), lds(lds_), lds_off(lane_ * 16) {}
@@ -165,7 +167,11 @@ struct WaveBackendT {
             Lm[r] = ej.lm;
             Rm[r] = ej.rm;
             w[r][0] = ej.w0; w[r][1] = ej.w1;
-            eco[r][0] = ej.e0; eco[r][1] = ej.e1; eco[r][2] = ej.e2; eco[r][3] = ej.e3;
+            if (F32BLK) {  // (e0, e2 | e1, e3): the row times (dN_a, dP_a), (dN_b, dP_b) is one packed multiply and one packed FMA
+                static_cast<float4 *>(lds)[(ECO0 + r) * 64 + lane] = float4{(float)ej.e0, (float)ej.e2, (float)ej.e1, (float)ej.e3};
+            } else {
+                eco[r][0] = ej.e0; eco[r][1] = ej.e1; eco[r][2] = ej.e2; eco[r][3] = ej.e3;
+            }
             mvv[r] = ej.mv;
         }
         cd = c * p.idx;
@@ -230,7 +236,10 @@ struct WaveBackendT {
             Ak = mneg(mmul(al, Akm));
             Ck = mneg(mmul(ga, Ckp));
         }
-        Bfin = minv(Bk);
+        if (F32BLK)
+            put(BFIN, minv(Bk));
+        else
+            Bfin = minv(Bk);
     }
 
     // ---- the re-solve with fp32-stored blocks: exchanged vectors and block products in packed fp32 ----
@@ -267,7 +276,7 @@ struct WaveBackendT {
         const v2f t = pb_acc(cr_ga, r0_up, pb_acc(cr_al, r0, v2f(0.0f)));
         // the reduced right-hand side goes through the six PCR levels as fp32: every product it meets is fp32 already
         v2f rk32 = narrow(V2{r[1].x - (double)t.x, r[1].y - (double)t.y});
-        PB b_inv = al, b_ia = al, b_ic = al;
+        PB b_inv = al, b_ia = al, b_ic = al, b_fin = al, e0 = al, e1 = al;
 #pragma unroll
         for (int lv = 0; lv < 6; ++lv) {
             const int s = 1 << lv;
@@ -275,10 +284,15 @@ struct WaveBackendT {
             if (lv < 5) {
                 al_n = get_pb(PAL0 + lv + 1);
                 ga_n = get_pb(PGA0 + lv + 1);
-            } else {
+            }
+            if (lv == 4) {
+                b_fin = get_pb(BFIN);
                 b_inv = get_pb(BINV_E);
+            } else if (lv == 5) {
                 b_ia = get_pb(BIA_E);
                 b_ic = get_pb(BIC_E);
+                e0 = get_pb(ECO0);
+                e1 = get_pb(ECO1);
             }
             const v2f rf = rk32;
             v2f rm, rp;
@@ -299,14 +313,14 @@ struct WaveBackendT {
             al = al_n;
             ga = ga_n;
         }
-        const V2 rk{(double)rk32.x, (double)rk32.y};
-        const V2 xk = mvec(Bfin, rk);
-        const V2 xk_prev = vprev(xk);
-        const v2f se = pb_acc(b_inv, r0, v2f(0.0f)) - pb_acc(b_ic, narrow(xk), pb_acc(b_ia, narrow(xk_prev), v2f(0.0f)));
-        const V2 xe{(double)se.x, (double)se.y};
-        x[0] = xe.x; x[1] = xk.x; x[2] = xe.y; x[3] = xk.y;
-        x[4] = b[4] * mvv[0] - (eco[0][0] * xk_prev.x + eco[0][1] * xe.x + eco[0][2] * xk_prev.y + eco[0][3] * xe.y);
-        x[5] = b[5] * mvv[1] - (eco[1][0] * xe.x + eco[1][1] * xk.x + eco[1][2] * xe.y + eco[1][3] * xk.y);
+        const v2f xk32 = pb_acc(b_fin, rk32, v2f(0.0f));
+        const v2f xkp32{from_prev(xk32.x), from_prev(xk32.y)};
+        const v2f se = pb_acc(b_inv, r0, v2f(0.0f)) - pb_acc(b_ic, xk32, pb_acc(b_ia, xkp32, v2f(0.0f)));
+        x[0] = (double)se.x; x[1] = (double)xk32.x; x[2] = (double)se.y; x[3] = (double)xk32.y;
+        // field back-substitution: the corrections of the densities are fp32 values here, so are the products
+        const v2f d0 = e0.ac * xkp32 + e0.bd * se, d1 = e1.ac * se + e1.bd * xk32;
+        x[4] = b[4] * mvv[0] - (double)(d0.x + d0.y);
+        x[5] = b[5] * mvv[1] - (double)(d1.x + d1.y);
     }
 
     // x = M^{-1} b; b, x in lane layout [N0,N1,P0,P1,E0,E1]

@@ -502,14 +502,14 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         MTRPL_STAMP(ph_ctl);
 
         // ---- simplified Newton on acor:  (I - h l0 J) dx = h f(y) - z[1] - acor,  y = z[0] + l0 acor ----
-        real acor[V], yn[V];
+        real acor[V];
         float acf[V];  // acor as fp32: what the norms see, and the next step's `acp`
         ctl dsm = 0.0f, ssel0 = 0.0f, ssel1 = 0.0f;
         int converged = 0, n_iter = 0, fresh = 0;
         for (;;) {  // with the kept factors, then once more with fresh ones
 #pragma unroll
-            for (int v = 0; v < V; ++v) { acor[v] = (real)0; yn[v] = z[0][v]; }
-            if (!have_fac) {
+            for (int v = 0; v < V; ++v) acor[v] = (real)0;
+            if (__builtin_expect(!have_fac, 0)) {  // one step in ten: spill code belongs around this block, not around the loop
                 // the analytic Jacobian is evaluated inside the factorisation: always at the predictor
                 MTRPL_STAMP(ph_glue);
                 bk.build(z[0], c);
@@ -524,6 +524,11 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             for (int k = 0; k < 4; ++k) {
                 n_iter = k + 1;
                 MTRPL_STAMP(ph_glue);
+                // the iterate is rebuilt from the correction where it is needed (six FMAs either way) instead of being
+                // carried through the re-solve next to it: twelve registers less at the kernel's tightest spot
+                real yn[V];
+#pragma unroll
+                for (int v = 0; v < V; ++v) yn[v] = fma(el0, acor[v], z[0][v]);
                 bk.rhs(yn, f);
                 MTRPL_STAMP(ph_rhs);
                 n_rhs++;
@@ -539,7 +544,6 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
                     acor[v] += dxv[v];
-                    yn[v] += el0 * dxv[v];
                     const float wv = (float)dxv[v] * isc[v];
                     acf[v] = (float)acor[v];
                     const float av = acf[v] * isc[v];
