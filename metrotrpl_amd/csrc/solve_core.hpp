@@ -195,29 +195,33 @@ __device__ inline void nq_rescale(T (&z)[6][V], T eta)
 struct Emitter {
     double *o;
     double min_y, scale;
-    double deep_below;  // deep_frac x |first sample|
-    double tail_below;  // tail_frac x |first sample|
-    double far_below;   // far_frac x |first sample|
-    double post_below;  // output level (absolute) below which the decay is low-injection
+    // The zones of the error-control policy are fractions of the first sample: one ratio per sample (fp32: the zone
+    // boundaries are policy, not results) against the fractions themselves, which are literals in the kernels with the
+    // shipped options compiled in -- four thresholds as doubles were eight registers of a kernel that spills.
+    double inv_first;   // 1 / |first sample|
+    float deep_frac, tail_frac, far_frac;
+    float post_frac;    // output level below which the decay is low-injection, as a fraction of the first sample
+    double post_level;  // ... absolute, until the first sample is known
     int clamped, deep, tail, far, post;
-    __device__ inline void begin(double *o_, double min_y_, double scale_, double deep_frac, double tail_frac, double far_frac,
-                                 double post_level)
+    __device__ inline void begin(double *o_, double min_y_, double scale_, double deep_frac_, double tail_frac_, double far_frac_,
+                                 double post_level_)
     {
         o = o_; min_y = min_y_; scale = scale_; clamped = 0; deep = 0; tail = 0; far = 0; post = 0;
-        deep_below = deep_frac;
-        tail_below = tail_frac;
-        far_below = far_frac;
-        post_below = post_level;
+        deep_frac = (float)deep_frac_;
+        tail_frac = (float)tail_frac_;
+        far_frac = (float)far_frac_;
+        post_level = post_level_;
+        post_frac = 0.0f;
+        inv_first = 0.0;
     }
     // total = dx-less grid sum; writer = this thread stores.  Every thread that calls sees the same v,
     // so `deep` is uniform among the callers.
     __device__ inline void first(double total, double dx, bool writer)
     {
         double v = total * dx * scale;
-        deep_below = deep_below * fabs(v);  // the first sample fixes the scale
-        tail_below = tail_below * fabs(v);
-        far_below = far_below * fabs(v);
-        post = !(fabs(v) >= post_below);
+        inv_first = 1.0 / fmax(fabs(v), 1e-300);  // the first sample fixes the scale
+        post_frac = (float)fmin(post_level * inv_first, 1e30);
+        post = !(1.0f >= post_frac);
         clamped = v < min_y;
         if (clamped) v = min_y;
         if (writer) o[0] = v;
@@ -225,10 +229,11 @@ struct Emitter {
     __device__ inline void put(int k, double total, double dx, bool writer)
     {
         double v = total * dx * scale;
-        deep |= !(fabs(v) >= deep_below);
-        tail |= !(fabs(v) >= tail_below);
-        far |= !(fabs(v) >= far_below);
-        post |= !(fabs(v) >= post_below);
+        const float r = (float)(fabs(v) * inv_first);
+        deep |= !(r >= deep_frac);
+        tail |= !(r >= tail_frac);
+        far |= !(r >= far_frac);
+        post |= !(r >= post_frac);
         clamped |= v < min_y;
         if (clamped) v = min_y;
         if (writer) o[k] = v;
