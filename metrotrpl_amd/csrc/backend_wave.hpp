@@ -12,7 +12,7 @@
 // further Newton iteration is a cheap re-solve.
 //
 // Kernels (bottom of the file): solve_kernel_wave1 / solve_kernel_wave2 -- the default: fp64 factorisation,
-// blocks stored as fp32 (17 KB of LDS per wave), re-solve in packed fp32 on an fp64 right-hand side; built
+// blocks stored as fp32 (20 KB of LDS per wave), re-solve in packed fp32 on an fp64 right-hand side; built
 // with the whole register file (one solve per SIMD: the shortest solve) and on a 256-register budget (two
 // solves per SIMD: the second wave fills the issue slots the first leaves waiting), same arithmetic, same
 // results.  solve_kernel_wave -- fp64 blocks (34 KB) and an fp64 re-solve: the exact linear algebra.
@@ -41,10 +41,10 @@ struct WaveBackendT {
     Emitter em;
     // factors
     double w[2][2];    // dJ/dbE weights per own edge
-    double eco[2][4];  // dE_i = bE_i*minv - eco.(dN_{i-1}, dN_i, dP_{i-1}, dP_i)
+    double eco[2][4];  // dE_i = bE_i*minv - eco.(dN_{i-1}, dN_i, dP_{i-1}, dP_i)   (fp64 blocks only; else LDS rows ECO0/1)
     double mvv[2];
     double cd;         // c/dx
-    M2 Bfin;
+    M2 Bfin;           // inverse of the last diagonal block of the PCR                  (fp64 blocks only; else LDS row BFIN)
     // The 17 elimination blocks (in-lane CR: Binv_e, BiA_e, BiC_e, cr_al, cr_ga; PCR: al[6], ga[6]) live
     // in this wave's LDS slab: [17 blocks][2 halves][64 lanes] x 16 B, i.e. every access is a
     // conflict-free ds_read/write_b128 (lane stride 16 B).
@@ -407,7 +407,8 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_wave(const mtrpl_solve_des
         integrate(bk, descs[sidx], ini, tsteps, out, status, stats, sidx, tune, clk0_);
 }
 
-// Two solves per SIMD: fp32-stored blocks (17 KB of LDS per wave, 8 waves per CU) and a 256-register budget.
+// Two solves per SIMD: fp32-stored blocks (20 KB of LDS per wave, 8 waves per CU = all of its 160 KB) and a
+// 256-register budget.
 template <bool CT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void solve_kernel_wave2(
     const mtrpl_solve_desc *__restrict__ descs, const double *__restrict__ ini, const double *__restrict__ tsteps,

@@ -12,6 +12,8 @@ cp $O/hbm_traffic_${T}_wave1.json profiles/hbm_traffic.json
 cp $O/hbm_traffic_${T}_wave2.json profiles/hbm_traffic_wave2.json
 # ---- the contract line (all legs: single stream, as given, sorted, fp64 linear algebra, PT) ----
 timeout -k 10 500 python bench.py --steps 30 --warmup 3 > $O/${T}_bench_config2.json 2> $O/${T}_bench.err
+# ... and over the K the driver times (its command line: --gpus 1 --steps 20 --warmup 5)
+timeout -k 10 200 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-pt > $O/${T}_bench_config2_k20.json 2>> $O/${T}_bench.err
 # ---- kernel statistics of the timed kind of launch, and of one launch at a time ----
 BENCH="python3 bench.py --steps 20 --warmup 1 --no-cpu-baseline --quick"
 BENCH1="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --streams 1 --quick"
