@@ -174,7 +174,26 @@ def _pt_leg(rank, world, local, dev, with_cpu):
     return out
 
 
+_STDOUT_FD = None
+
+
+def emit(line):
+    """The ONE line of the contract, on the real stdout (see main)."""
+    data = (json.dumps(line) + "\n").encode()
+    if _STDOUT_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_STDOUT_FD, data)
+
+
 def main():
+    # Libraries below this process write to file descriptor 1 on their own (RCCL prints a version banner when the first
+    # communicator is made): everything but the contract line goes to stderr.
+    global _STDOUT_FD
+    sys.stdout.flush()
+    _STDOUT_FD = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -242,7 +261,7 @@ def main():
         from metrotrpl_amd import pt_bench
         line = pt_bench.run(a, rank, world, local, dev, cpu_baseline_fn=cpu_baseline_pt)
         if rank == 0:
-            print(json.dumps(line))
+            emit(line)
         if use_dist:
             dist.destroy_process_group()
         return
@@ -250,7 +269,7 @@ def main():
         from metrotrpl_amd import config5_bench
         line = config5_bench.run(a, rank, world, local, dev)
         if rank == 0:
-            print(json.dumps(line))
+            emit(line)
         if use_dist:
             dist.destroy_process_group()
         return
@@ -457,7 +476,7 @@ def main():
         line["accuracy"] = acc
         if pt_leg is not None:
             line["pt"] = pt_leg
-        print(json.dumps(line))
+        emit(line)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -139,6 +139,8 @@ const char *mtrpl_version(void);
  *                                     the first sample (default 1e-11: the state sits at equilibrium to rounding) the
  *                                     error test alone sets the step for the rest of the solve (the flag latches and is
  *                                     evaluated at output samples); 0: desc.hmax always holds
+ *   deep_factor                       ... and from that sample on the local tolerance is multiplied by deep_factor (default 1000) on top
+ *                                     of far_factor: eleven decades down no sample is resolved, and none is gated
  *   fresh_jac                         accepted and ignored (removed in round 2: the Jacobian is always refreshed at a
  *                                     refactorisation)
  *   max_steps                         a solve that needs more stops early (status 1, tail zero-filled)

@@ -467,7 +467,7 @@ const OptD kOptD[] = {
     {"nq_bias_up", &SolveTuning::nq_bias_up}, {"early_factor", &SolveTuning::early_factor},
     {"early_frac", &SolveTuning::early_frac}, {"hmax_deep", &SolveTuning::hmax_deep},
     {"hmax_scale", &SolveTuning::hmax_scale}, {"tail_frac", &SolveTuning::tail_frac}, {"tail_factor", &SolveTuning::tail_factor},
-    {"far_frac", &SolveTuning::far_frac}, {"far_factor", &SolveTuning::far_factor},
+    {"far_frac", &SolveTuning::far_frac}, {"far_factor", &SolveTuning::far_factor}, {"deep_factor", &SolveTuning::deep_factor},
 };
 const OptI kOptI[] = {
     {"max_steps", &SolveTuning::max_steps}, {"rate_max_age", &SolveTuning::rate_max_age},

@@ -76,6 +76,8 @@ struct SolveTuning {
     double e_weight;    // relative error weight of the field components = e_weight * rtol_int (TRPL solves)
     int honor_hmax;     // 1: desc.hmax caps the step (the reference's max_step); 0: error control alone
     double hmax_deep;   // ... until the signal has fallen below this fraction of its first sample (0: always)
+    double deep_factor; // ... from where on the local tolerance is multiplied by this as well (the state sits at
+                        // equilibrium to rounding: no sample down there is resolved or gated)
     double hmax_scale;  // the cap is hmax_scale x desc.hmax
     double tail_frac;   // once the signal has fallen below this fraction of its first sample ...
     double tail_factor; // ... the local tolerance is multiplied by this (< 1: the relative error of a long decay
@@ -104,14 +106,14 @@ struct DefaultTune {
     static constexpr int rate_max_age = 8;
     static constexpr double rate_first_safety = 4.0, e_weight = 3.0;
     static constexpr int honor_hmax = 1;
-    static constexpr double hmax_deep = 1e-11, hmax_scale = 1.0, tail_frac = 1e-4, tail_factor = 0.4, far_frac = 1e-9, far_factor = 3.0, trts_rtol_factor = 0.5, amp_ref = 10.0, amp_post = 0.03, nq_deadband_hi = 1.2;
+    static constexpr double hmax_deep = 1e-11, deep_factor = 1000.0, hmax_scale = 1.0, tail_frac = 1e-4, tail_factor = 0.4, far_frac = 1e-9, far_factor = 3.0, trts_rtol_factor = 0.5, amp_ref = 10.0, amp_post = 0.03, nq_deadband_hi = 1.2;
     static constexpr int nq_rej_memory = 80;
     static constexpr double nq_rej_growth = 1.2, nq_bias_same = 1.0, nq_bias_down = 1.0, nq_bias_up = 1.0;
     static constexpr double early_factor = 10.0, early_frac = 0.5;
     static SolveTuning make()
     {
         return SolveTuning{rtol_scale, rtol_cap, rtol_floor, rtol_min, rtol_force, atol_rel, atol_rel_np, max_steps,
-                           newton_tol, rate_max_age, rate_first_safety, e_weight, honor_hmax, hmax_deep, hmax_scale, tail_frac, tail_factor, far_frac, far_factor, trts_rtol_factor,
+                           newton_tol, rate_max_age, rate_first_safety, e_weight, honor_hmax, hmax_deep, deep_factor, hmax_scale, tail_frac, tail_factor, far_frac, far_factor, trts_rtol_factor,
                            amp_ref, amp_post, nq_deadband_hi, nq_rej_memory, nq_rej_growth, nq_bias_same, nq_bias_down, nq_bias_up,
                            early_factor, early_frac};
     }
@@ -368,7 +370,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
     const ctl rtol_f = (ctl)rtol, rtol_E_f = (ctl)rtol_E, atol_f = (ctl)atol, atol_E_f = (ctl)atol_E;
     const real early_until = (nt > 1) ? (real)(tune.early_frac * ts[1]) : (real)0;
     const ctl early_mul = (ctl)(1.0 / fmax(tune.early_factor, 1.0));  // norms of an early step are scaled by this
-    const ctl tail_mul = (ctl)(1.0 / tune.tail_factor), far_mul = (ctl)(1.0 / tune.far_factor), amp_mul = (ctl)amp_mul_d;
+    const ctl tail_mul = (ctl)(1.0 / tune.tail_factor), far_mul = (ctl)(1.0 / tune.far_factor), deep_mul = (ctl)(1.0 / (tune.far_factor * tune.deep_factor)), amp_mul = (ctl)amp_mul_d;
     const ctl newton_tol = (tune.newton_tol > 0.0)
                                ? (ctl)tune.newton_tol
                                : (ctl)fmax(10.0 * 2.220446049250313e-16 / (double)rtol, fmin(0.03, sqrt((double)rtol)));
@@ -493,7 +495,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         // (far_factor x)
         // ... and the steps of a tauP >> tauN solve amp x tighter while its decay is high-injection
         const ctl nscale = ((tune.early_factor > 1.0 && t + h <= early_until) ? early_mul
-                                                                              : (bk.far() ? far_mul : (bk.tail() ? tail_mul : 1.0f))) *
+                                                                              : (bk.deep() ? deep_mul : (bk.far() ? far_mul : (bk.tail() ? tail_mul : 1.0f)))) *
                            (bk.post() ? 1.0f : amp_mul);
         // error weights of this step, 1/(atol + rtol |y_predicted|), fp32
         float isc[V];

@@ -48,17 +48,19 @@ def test_tight_rtol_is_honoured_loose_rtol_is_not_a_licence():
 
 
 def test_atol_bounds_the_absolute_term():
-    """ATOL is an upper bound of the densities' absolute tolerance.  Measured with the far-tail relaxation off
-    (far_factor = 1: by default the local tolerance is loosened again nine decades down, where nothing is resolved,
-    and would mask what the absolute term does there)."""
+    """ATOL is an upper bound of the densities' absolute tolerance.  Measured with the far-tail relaxations off
+    (far_factor = deep_factor = 1: by default the local tolerance is loosened again nine and eleven decades down, where
+    nothing is resolved, and would mask what the absolute term does there)."""
     from metrotrpl_amd import _lib as L
     ctx = L.default_context()
     ctx.set_option("far_factor", 1.0)
+    ctx.set_option("deep_factor", 1.0)
     try:
         _atol_case()
     finally:
         ctx.set_option("far_factor", 3.0)
-    assert ctx.get_option("far_factor") == 3.0
+        ctx.set_option("deep_factor", 1000.0)
+    assert ctx.get_option("far_factor") == 3.0 and ctx.get_option("deep_factor") == 1000.0
 
 
 def _atol_case():
