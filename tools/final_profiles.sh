@@ -3,6 +3,8 @@
 # gpurun AFTER the last code commit; everything lands in gpurun_out/, tools/collect_profiles.sh copies it to profiles/)
 T=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+# bench.py sets this itself, but under rocprofv3 the runtime is up before Python starts
+export GPU_MAX_HW_QUEUES=8
 O=gpurun_out
 # ---- counters of the two builds of the wave kernel (each group in its own pass) ----
 tools/pmc.sh $T > $O/${T}_pmc.log 2>&1
