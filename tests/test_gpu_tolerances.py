@@ -79,3 +79,34 @@ def _atol_case():
     assert e_deep < 0.9 * e_base  # (two-fold with round 2's ten times larger default floor)
     # the field keeps its own absolute floor: a tiny ATOL does not send the integrator crawling
     assert stats2[:, 0].max() < 3 * stats0[:, 0].max()
+
+
+def test_deep_zone_relaxation_touches_no_sample_above_it():
+    """Eleven decades below its first sample a solve's local tolerance is relaxed by deep_factor (default 1000) and the
+    reference's max_step is lifted (hmax_deep).  The zone is entered at an output sample, so every sample up to and
+    including the first one below 1e-11 x the first is the SAME BITS with and without the relaxation; what comes after
+    stays a decaying tail of that size, and solves that never get there do not change at all."""
+    from metrotrpl_amd import _lib as L
+    z = np.load(os.path.join(G, "tail_decades.npz"))
+    sel = np.arange(256, 256 + 96)  # the config-3 geometry: thin films decay through many decades
+    ctx = L.default_context()
+    shipped, st0, stats0 = _solve(z, sel)
+    ctx.set_option("deep_factor", 1.0)
+    try:
+        plain, st1, stats1 = _solve(z, sel)
+    finally:
+        ctx.set_option("deep_factor", 1000.0)
+    assert np.all(st0 == 0) and np.all(st1 == 0)
+    n_deep = 0
+    for a, b in zip(shipped, plain):
+        below = np.flatnonzero(np.abs(b) < 1e-11 * abs(b[0]))
+        if below.size == 0:
+            np.testing.assert_array_equal(a, b)
+            continue
+        n_deep += 1
+        k = below[0]
+        np.testing.assert_array_equal(a[:k + 1], b[:k + 1])
+        assert np.all(np.abs(a[k + 1:]) < 1e-10 * abs(a[0]))
+    assert n_deep >= 10, n_deep  # the fixture does reach down there
+    assert stats0[:, 0].sum() < stats1[:, 0].sum()
+    print(f"{n_deep} of {len(sel)} traces reach the zone; steps {stats1[:, 0].mean():.0f} -> {stats0[:, 0].mean():.0f}")
