@@ -212,20 +212,49 @@ def pmc_fields(solves_per_launch=1024, kernel="solve_kernel_wave1"):
 N_SIMD, CLOCK_HZ = 1024, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz max clock
 
 
+# Issue cost of the instruction classes with two waves per SIMD, cycles per wave-instruction per SIMD, measured on this
+# device by tools/mb/rcp_rate.hip (profiles/r03_z_issue_cost.txt: v_add_f64 2.05 ns, v_fma_f64 2.52 ns, v_rcp_f64 7.9 ns
+# per wave-op per SIMD at 2.3 GHz; a wave ALONE on its SIMD issues an fp64 instruction only every 8 cycles)
+ISSUE_COST_2WAVES = {"SQ_INSTS_VALU_ADD_F64": 4.7, "SQ_INSTS_VALU_FMA_F64": 5.8, "SQ_INSTS_VALU_MUL_F64": 5.8,
+                     "SQ_INSTS_VALU_TRANS_F64": 18.0, "SQ_INSTS_VALU_ADD_F32": 4.0, "SQ_INSTS_VALU_FMA_F32": 4.0,
+                     "SQ_INSTS_VALU_MUL_F32": 4.0, "SQ_INSTS_VALU_TRANS_F32": 8.0, "other": 4.0}
+
+
 def valu_issue_fields(kernel, solves_per_sec_per_gpu):
     """The binding roofline of the solve kernel: vector-ALU issue.  Instructions and VALU-busy cycles per solve
     come from the committed rocprofv3 --pmc SQ_* pass of the named kernel (not measured in this run); frac = the
     share of the device's SIMD-cycles (1024 SIMDs x 2.4 GHz nominal) the measured solve rate keeps the vector
-    ALUs busy."""
+    ALUs busy BY THE COUNTER, which books four cycles per instruction.  An fp64 instruction occupies the pipeline
+    longer than that (ISSUE_COST_2WAVES): `throughput` prices the kernel's own instruction mix (a second --pmc pass,
+    profiles/hbm_traffic_mix_wave2.json) with the measured costs -- the time the SIMD needs to issue one solve's
+    instructions with nothing ever waiting -- and frac_of_bound is the measured rate against that."""
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     name = "hbm_traffic_wave2.json" if kernel.endswith("wave2") else "hbm_traffic.json"
     try:
         z = json.load(open(os.path.join(repo, "profiles", name)))
         sq, d = z["sq_counters_per_launch"], z["derived"]
         busy = 4.0 * sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVES"]  # SQ_ACTIVE_* count quad-cycles
-        return {"insts_per_solve": d["valu_insts_per_solve"], "busy_cycles_per_solve": busy,
-                "frac": solves_per_sec_per_gpu * busy / (N_SIMD * CLOCK_HZ), "peak": "1024 SIMDs x 2.4 GHz",
-                "source": f"profiles/{name} (rocprofv3 --pmc SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_WAVES of {kernel}); "
-                          "the solve rate is this run's"}
+        out = {"insts_per_solve": d["valu_insts_per_solve"], "busy_cycles_per_solve": busy,
+               "frac": solves_per_sec_per_gpu * busy / (N_SIMD * CLOCK_HZ), "peak": "1024 SIMDs x 2.4 GHz",
+               "source": f"profiles/{name} (rocprofv3 --pmc SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_WAVES of {kernel}); "
+                         "the solve rate is this run's"}
+        if kernel.endswith("wave2"):
+            try:
+                mix = json.load(open(os.path.join(repo, "profiles", "hbm_traffic_mix_wave2.json")))["per_solve"]
+                classed = sum(v for k, v in mix.items() if k != "SQ_INSTS_VALU")
+                cycles = sum(ISSUE_COST_2WAVES[k] * v for k, v in mix.items() if k != "SQ_INSTS_VALU")
+                cycles += ISSUE_COST_2WAVES["other"] * (mix["SQ_INSTS_VALU"] - classed)
+                out["throughput"] = {
+                    "fp64_insts_per_solve": sum(v for k, v in mix.items() if k.endswith("_F64")),
+                    "fp32_insts_per_solve": sum(v for k, v in mix.items() if k.endswith("_F32")),
+                    "other_insts_per_solve": mix["SQ_INSTS_VALU"] - classed,
+                    "issue_cycles_per_solve": cycles,
+                    "bound_solves_per_sec": N_SIMD * CLOCK_HZ / cycles,
+                    "frac_of_bound": solves_per_sec_per_gpu * cycles / (N_SIMD * CLOCK_HZ),
+                    "source": "profiles/hbm_traffic_mix_wave2.json (instruction classes, rocprofv3 --pmc) x the issue costs "
+                              "measured by tools/mb/rcp_rate.hip with two waves per SIMD (profiles/r03_z_issue_cost.txt)"}
+            except Exception as e:
+                out["throughput"] = {"error": repr(e)}
+        return out
     except Exception as e:
         return {"error": repr(e)}

@@ -8,10 +8,12 @@ export GPU_MAX_HW_QUEUES=8
 O=gpurun_out
 # ---- counters of the two builds of the wave kernel (each group in its own pass) ----
 tools/pmc.sh $T > $O/${T}_pmc.log 2>&1
+tools/pmc_mix.sh $T > $O/${T}_pmc_mix.log 2>&1
 # the bench line quotes VALU instructions / busy cycles / HBM bytes per solve from the committed summaries: put this
 # build's in place first (tools/collect_profiles.sh makes the same copy in the repository)
 cp $O/hbm_traffic_${T}_wave1.json profiles/hbm_traffic.json
 cp $O/hbm_traffic_${T}_wave2.json profiles/hbm_traffic_wave2.json
+cp $O/hbm_traffic_${T}_mix_wave2.json profiles/hbm_traffic_mix_wave2.json
 # ---- the contract line (all legs: single stream, as given, sorted, fp64 linear algebra, PT) ----
 timeout -k 10 500 python bench.py --steps 30 --warmup 3 > $O/${T}_bench_config2.json 2> $O/${T}_bench.err
 # ... and over the K the driver times (its command line: --gpus 1 --steps 20 --warmup 5)
