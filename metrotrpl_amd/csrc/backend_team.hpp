@@ -145,10 +145,10 @@ struct TeamBackend {
         return v;
     }
     __device__ inline void out_begin(double *o, double min_y, double scale, double deep, double tail, double far, double post) { em.begin(o, min_y, scale, deep, tail, far, post); }
-    __device__ inline bool post() const { return em.post != 0; }
-    __device__ inline bool tail() const { return em.tail != 0; }
-    __device__ inline bool far() const { return em.far != 0; }
-    __device__ inline bool deep() const { return em.deep != 0; }
+    __device__ inline bool post() const { return em.post(); }
+    __device__ inline bool tail() const { return em.tail(); }
+    __device__ inline bool far() const { return em.far(); }
+    __device__ inline bool deep() const { return em.deep(); }
     __device__ inline real team_sum(real partial)
     {
         // full-precision sum (reduce_f() is the controller-grade one)

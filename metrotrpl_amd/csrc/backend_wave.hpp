@@ -91,10 +91,10 @@ struct WaveBackendT {
     __device__ inline double scan_excl(double run) const { return wave_scan_incl(run, lane) - run; }
     __device__ inline double max_all(double v) const { return wave_max(v); }
     __device__ inline void out_begin(double *o, double min_y, double scale, double deep, double tail, double far, double post) { em.begin(o, min_y, scale, deep, tail, far, post); }
-    __device__ inline bool post() const { return em.post != 0; }
-    __device__ inline bool tail() const { return em.tail != 0; }
-    __device__ inline bool far() const { return em.far != 0; }
-    __device__ inline bool deep() const { return em.deep != 0; }
+    __device__ inline bool post() const { return em.post(); }
+    __device__ inline bool tail() const { return em.tail(); }
+    __device__ inline bool far() const { return em.far(); }
+    __device__ inline bool deep() const { return em.deep(); }
     __device__ inline void out_first(double partial) { em.first(uniform(wave_sum(partial)), p.dx, lane == 0); }
     __device__ inline void out_sample(int k, double partial) { em.put(k, uniform(wave_sum(partial)), p.dx, lane == 0); }
 

@@ -197,33 +197,41 @@ __device__ inline void nq_rescale(T (&z)[6][V], T eta)
 struct Emitter {
     double *o;
     double min_y, scale;
-    // The zones of the error-control policy are fractions of the first sample: one ratio per sample (fp32: the zone
-    // boundaries are policy, not results) against the fractions themselves, which are literals in the kernels with the
-    // shipped options compiled in -- four thresholds as doubles were eight registers of a kernel that spills.
+    // The zones of the error-control policy are fractions of the first sample.  Per sample ONE ratio (fp32: the zone
+    // boundaries are policy, not results) folded into a running minimum; the four zone tests are made where a step
+    // asks for them, against fractions that are literals in the kernels with the shipped options compiled in.  (Four
+    // fp64 thresholds were eight registers of a kernel that spills, and four sticky integer flags three vector
+    // instructions each per sample: compare, select 0/1, or.)
     double inv_first;   // 1 / |first sample|
+    float rmin;         // smallest |sample| / |first sample| so far
     float deep_frac, tail_frac, far_frac;
     float post_frac;    // output level below which the decay is low-injection, as a fraction of the first sample
     double post_level;  // ... absolute, until the first sample is known
-    int clamped, deep, tail, far, post;
+    int clamped;
     __device__ inline void begin(double *o_, double min_y_, double scale_, double deep_frac_, double tail_frac_, double far_frac_,
                                  double post_level_)
     {
-        o = o_; min_y = min_y_; scale = scale_; clamped = 0; deep = 0; tail = 0; far = 0; post = 0;
+        o = o_; min_y = min_y_; scale = scale_; clamped = 0;
         deep_frac = (float)deep_frac_;
         tail_frac = (float)tail_frac_;
         far_frac = (float)far_frac_;
         post_level = post_level_;
         post_frac = 0.0f;
         inv_first = 0.0;
+        rmin = 1.0f;
     }
+    __device__ inline bool deep() const { return !(rmin >= deep_frac); }
+    __device__ inline bool tail() const { return !(rmin >= tail_frac); }
+    __device__ inline bool far() const { return !(rmin >= far_frac); }
+    __device__ inline bool post() const { return !(rmin >= post_frac); }
     // total = dx-less grid sum; writer = this thread stores.  Every thread that calls sees the same v,
-    // so `deep` is uniform among the callers.
+    // so the zones are uniform among the callers.
     __device__ inline void first(double total, double dx, bool writer)
     {
         double v = total * dx * scale;
         inv_first = 1.0 / fmax(fabs(v), 1e-300);  // the first sample fixes the scale
         post_frac = (float)fmin(post_level * inv_first, 1e30);
-        post = !(1.0f >= post_frac);
+        rmin = 1.0f;
         clamped = v < min_y;
         if (clamped) v = min_y;
         if (writer) o[0] = v;
@@ -231,11 +239,7 @@ struct Emitter {
     __device__ inline void put(int k, double total, double dx, bool writer)
     {
         double v = total * dx * scale;
-        const float r = (float)(fabs(v) * inv_first);
-        deep |= !(r >= deep_frac);
-        tail |= !(r >= tail_frac);
-        far |= !(r >= far_frac);
-        post |= !(r >= post_frac);
+        rmin = fminf(rmin, (float)(fabs(v) * inv_first));
         clamped |= v < min_y;
         if (clamped) v = min_y;
         if (writer) o[k] = v;
