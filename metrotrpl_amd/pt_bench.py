@@ -215,6 +215,8 @@ N_SIMD, CLOCK_HZ = 1024, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GH
 # Issue cost of the instruction classes with two waves per SIMD, cycles per wave-instruction per SIMD, measured on this
 # device by tools/mb/rcp_rate.hip (profiles/r03_z_issue_cost.txt: v_add_f64 2.05 ns, v_fma_f64 2.52 ns, v_rcp_f64 7.9 ns
 # per wave-op per SIMD at 2.3 GHz; a wave ALONE on its SIMD issues an fp64 instruction only every 8 cycles)
+# (packed fp32 instructions are counted in the fp32 classes at 4 cycles although they cost about 6: the bound is
+# optimistic by about 4 %)
 ISSUE_COST_2WAVES = {"SQ_INSTS_VALU_ADD_F64": 4.7, "SQ_INSTS_VALU_FMA_F64": 5.8, "SQ_INSTS_VALU_MUL_F64": 5.8,
                      "SQ_INSTS_VALU_TRANS_F64": 18.0, "SQ_INSTS_VALU_ADD_F32": 4.0, "SQ_INSTS_VALU_FMA_F32": 4.0,
                      "SQ_INSTS_VALU_MUL_F32": 4.0, "SQ_INSTS_VALU_TRANS_F32": 8.0, "other": 4.0}
