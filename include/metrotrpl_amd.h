@@ -112,9 +112,9 @@ const char *mtrpl_version(void);
 /* Integrator options.  Unknown key -> MTRPL_ERR_BAD_ARG.
  *   rtol_scale, rtol_cap              internal rtol = min(rtol_scale * desc.rtol, rtol_cap) ...
  *   trts_rtol_factor                  ... x this for TRTS solves ...
- *   amp_ref, amp_post                 ... / max(1, (1 + tauP/tauN) / amp_ref) (0 = off; default 10) while the emitted signal
- *                                     is above amp_post x its first sample (default 0.03: until the high- to low-injection
- *                                     transition is behind the solve) ...
+ *   amp_ref, amp_post                 ... / max(1, (1 + tauP/tauN) / amp_ref) (0 = off; default 10) while the excess density is
+ *                                     above amp_post x p0 (default 0.03; judged by the emitted signal: until the high- to
+ *                                     low-injection transition is behind the solve) ...
  *   tail_frac, tail_factor            ... x tail_factor (0.4) once an emitted sample has fallen below tail_frac (1e-4) x the
  *                                     first one, where the signal is a small difference of the state ...
  *   far_frac, far_factor              ... x far_factor (3) instead below far_frac (1e-9): nothing measured reaches there ...

@@ -525,6 +525,7 @@ int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value)
     else if (k == "two_per_simd_min_batch") *value = ctx->two_per_simd_min_batch;
     else if (k == "order_min_batch") *value = ctx->order_min_batch;
     else if (k == "precision") *value = ctx->precision;
+    else if (k == "fresh_jac") *value = 0.0;  // accepted and ignored (set_option)
     else return MTRPL_ERR_BAD_ARG;
     return MTRPL_OK;
 }

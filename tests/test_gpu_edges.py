@@ -1,6 +1,7 @@
 """GPU edge cases through the C ABI: empty and ragged batches, tiny grids, a single
 sample time, mixed measurement types and grid sizes in one launch, integrator give-up."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -166,3 +167,27 @@ def test_launch_order_is_a_permutation_by_cost_and_changes_no_result():
         ctx.set_option("order_min_batch", 256)
     np.testing.assert_array_equal(sig, sig0)
     np.testing.assert_array_equal(stats[:, :7], stats0[:, :7])
+
+
+def test_every_option_the_header_documents_exists():
+    """include/metrotrpl_amd.h lists the integrator options in the comment above mtrpl_set_option: each of them is
+    a key the library knows (get works, set of the same value works), and an unknown key is an error."""
+    import re
+    from metrotrpl_amd import _lib as L
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "metrotrpl_amd.h")).read()
+    block = hdr[hdr.index("/* Integrator options"):hdr.index("int mtrpl_set_option")]
+    keys = []
+    for line in block.splitlines():
+        m = re.match(r"^ \*   ([a-z_0-9]+(?:, [a-z_0-9/]+)*)\s{2,}", line)
+        if m:
+            for k in m.group(1).split(", "):
+                keys.extend(k.split("/"))
+    keys = [k if not k.startswith("_") else "nq_bias" + k for k in keys]
+    assert len(keys) >= 30, keys
+    ctx = L.default_context()
+    for k in keys:
+        v = ctx.get_option(k)
+        ctx.set_option(k, v)
+        assert ctx.get_option(k) == v, k
+    with pytest.raises(Exception):
+        ctx.get_option("no_such_option")
