@@ -84,3 +84,19 @@ def test_round3_bench_line_tells_the_whole_story():
     assert acc["all_ok"] is True and max(acc["max_rel_err_per_decade_0_to_8"]) < 1.01e-6
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "solves/s"
+
+
+def test_without_a_gpu_bench_fails_loudly_and_prints_no_line():
+    """The HIP path has no CPU fallback: without a device bench.py says so on stderr, exits non-zero and leaves stdout
+    empty (the only thing it ever writes there is the one contract line)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a machine without a GPU")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--no-cpu-baseline"], capture_output=True, text=True,
+                       cwd=REPO, timeout=300)
+    assert r.returncode == 3, (r.returncode, r.stderr[-300:])
+    assert r.stdout == ""
+    assert "no GPU visible" in r.stderr
