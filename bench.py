@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X forward-solver engine.
 
-    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its N ranks itself, as a
+                                                            child `python -m torch.distributed.run`, and relays the line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1], SURVEY.md 8d "Config 2"): a 1024-solve
@@ -14,12 +15,11 @@ synthetic batch per GPU, nx=128, thickness 2000 nm, 1001 output times over
 The K timed steps are independent batches, so they are issued the way a caller with
 more than one batch to do issues them: round-robin on four HIP streams (with the runtime's
 GPU_MAX_HW_QUEUES raised from 4 to 8, so that no two of them share a hardware queue), on the
-two-solves-per-SIMD form of the wave kernel, every batch handed over AS DRAWN -- a solve
-holds its SIMD slot for its whole duration and durations spread 1:1.5, so the slots the
-short solves of one launch free go to the next launch.  Inside a launch the library issues
-the solves by descending EXPECTED cost, a model of the descriptors alone (csrc/launch_order.hpp):
-nothing is measured beforehand.  Measured in the same run and reported beside it:
-  as_given                 the timed region with that ordering switched off (order_min_batch = 0)
+two-solves-per-SIMD form of the wave kernel, every batch handed over AS DRAWN and issued in
+that order -- a solve holds its SIMD slot for its whole duration and durations spread 1:1.5,
+so the slots the short solves of one launch free go to the next launch.  (Round 3's issue
+ordering by a cost model -- two small kernels in front of every launch -- bought 1.6 % and
+is gone.)  Measured in the same run and reported beside it:
   single_stream            the same K steps back to back on ONE stream, one solve per
                            SIMD: every launch alone on the device (latency, the kernel's own speed)
   sorted_by_measured_cost  ... and with each batch's solves issued longest first by the cost
@@ -153,23 +153,41 @@ def _cpu_one(k):
     return k
 
 
-def _pt_leg(rank, world, local, dev, with_cpu):
+def _pt_leg(rank, world, local, dev, with_cpu, use_dist=False):
     """BASELINE.json's second metric, measured in the same run: a few iterations of the 64-chain (config 3) and
     the 512-chain (config 4 on this many GPUs) parallel-tempering ensembles through metrotrpl_amd.pt_bench.run."""
     import types
     from metrotrpl_amd import pt_bench
     out = {}
-    for chains, steps, warm in ((64, 30, 10), (512, 10, 10)):
+
+    def leg(chains, steps, warm, rank_, world_, use_dist_, cpu_):
         a = types.SimpleNamespace(chains=chains, steps=steps, warmup=warm, prefetch="auto", groups=0, opt=[],
-                                  use_dist=world > 1, no_cpu_baseline=not (with_cpu and chains == 64))
+                                  use_dist=use_dist_, no_cpu_baseline=not cpu_)
+        ln = pt_bench.run(a, rank_, world_, local, dev, cpu_baseline_fn=cpu_baseline_pt)
+        return {"chains": chains, "n_gpus": world_, "iterations": steps, "warmup": warm,
+                "ms_per_iteration": ln["ms_per_step"], "proposals_per_sec": ln["value"],
+                "forward_solves_per_sec": ln["config"]["forward_solves_per_sec"],
+                "prefetch": ln["config"]["prefetch"], "chain_groups": ln["config"]["chain_groups"],
+                "collectives_per_iteration": ln["config"].get("collectives_per_iteration"),
+                "max_integrator_steps_per_rank": ln["config"].get("max_integrator_steps_per_rank"),
+                **({"cpu_baseline": ln["cpu_baseline"]} if "cpu_baseline" in ln else {})}
+
+    for chains, steps, warm in ((64, 30, 10), (512, 10 if world == 1 else 30, 10)):
         try:
-            ln = pt_bench.run(a, rank, world, local, dev, cpu_baseline_fn=cpu_baseline_pt)
-            out[str(chains)] = {"chains": chains, "iterations": steps, "warmup": warm,
-                                "ms_per_iteration": ln["ms_per_step"], "proposals_per_sec": ln["value"],
-                                "forward_solves_per_sec": ln["config"]["forward_solves_per_sec"],
-                                "prefetch": ln["config"]["prefetch"], "chain_groups": ln["config"]["chain_groups"],
-                                "collectives_per_iteration": ln["config"].get("collectives_per_iteration"),
-                                **({"cpu_baseline": ln["cpu_baseline"]} if "cpu_baseline" in ln else {})}
+            # the 64-chain ensemble is config 3, a ONE-GPU configuration: at N > 1 rank 0 runs it alone
+            if chains == 64 and world > 1:
+                if rank == 0:
+                    out["64"] = leg(64, steps, warm, 0, 1, False, False)
+                continue
+            out[str(chains)] = leg(chains, steps, warm, rank, world, use_dist, with_cpu and chains == 64)
+            if chains == 512 and world > 1:
+                # strong scaling: the same 512-chain ensemble of the same build on ONE GPU (rank 0, the others wait
+                # at the barrier below), so that the line carries its own N = 1 figure
+                out["512"]["scaling"] = "strong"
+                if rank == 0:
+                    one = leg(512, 10, 10, 0, 1, False, False)
+                    out["512"]["one_gpu_same_build"] = one
+                    out["512"]["speedup_vs_one_gpu"] = one["ms_per_iteration"] / out["512"]["ms_per_iteration"]
         except Exception as e:  # the solves/s contract line must not depend on this leg
             out[str(chains)] = {"error": repr(e)}
     return out
@@ -186,6 +204,41 @@ def emit(line):
         sys.stdout.flush()
     else:
         os.write(_STDOUT_FD, data)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as a CHILD
+    `python -m torch.distributed.run` (never an exec, and before this process has made any GPU call -- counting devices
+    does not initialise the runtime), relay rank 0's contract line to the real stdout and return the child's exit code.
+    Without N visible GPUs nothing is started: exit code 3, nothing on stdout (there is no CPU fallback)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} but {have} GPU(s) visible; the HIP path has no CPU fallback", file=sys.stderr)
+        return 3
+    with socket.socket() as s:  # a free rendezvous port on the loop-back interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: starting the ranks: " + " ".join(cmd), file=sys.stderr)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None)
+    out, _ = child.communicate()
+    line = None
+    for ln in out.decode(errors="replace").splitlines():  # the launcher may talk on stdout too: the contract line only
+        try:
+            if "metric" in json.loads(ln):
+                line = ln
+        except (ValueError, TypeError):
+            print(ln, file=sys.stderr)
+    if line is not None and child.returncode == 0:
+        os.write(_STDOUT_FD, (line + "\n").encode())
+    elif child.returncode == 0:
+        print("bench.py: the ranks ended without a contract line", file=sys.stderr)
+        return 1
+    return child.returncode
 
 
 def main():
@@ -230,6 +283,8 @@ def main():
                     help="integrator option for experiments (mtrpl_set_option); reported in config.options")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -373,16 +428,8 @@ def main():
         single = (dt, kern_ms, ok)
     status = d_status.cpu().numpy()
     stats = d_stats.cpu().numpy().reshape(B, 8)
-    # ---- (3) the same region as given (no ordering at all), and with each batch's solves longest first by the
-    #          cost measured on the identical batch (the library's own ordering off in both) ----
-    given_leg = None
+    # ---- (3) the same region with each batch's solves longest first by the cost measured on the identical batch ----
     if not a.quick and S > 1 and not a.sort_by_cost:
-        order_min = ctx.get_option("order_min_batch")
-        ctx.set_option("order_min_batch", 0)
-        for k in range(S):
-            step(k)
-        torch.cuda.synchronize()
-        given_leg = timed(S)
         order = np.argsort(-stats_drawn[:, 7], kind="stable")
         cur["descs"] = torch.from_numpy(descs[order].view(np.uint8).reshape(-1)).to(dev)
         for k in range(S):
@@ -390,7 +437,6 @@ def main():
         torch.cuda.synchronize()
         sorted_leg = timed(S)
         cur["descs"] = d_descs_drawn
-        ctx.set_option("order_min_batch", order_min)
 
     # measured HBM stream rate of this device (read + write of a 1 GiB buffer), next to the nominal peak
     copy_gbs = None
@@ -420,7 +466,7 @@ def main():
     pt_leg = None
     if not a.quick and not a.no_pt and not user_variant:
         del outs, d_out, d_status, d_stats
-        pt_leg = _pt_leg(rank, world, local, dev, with_cpu=(cpu is not None))
+        pt_leg = _pt_leg(rank, world, local, dev, with_cpu=(cpu is not None), use_dist=use_dist)
     if rank == 0:
         A = algorithmic_bytes_per_solve(c["nx"], nt)
         achieved = A * B / (kern_ms * 1e-3) / 1e9
@@ -447,15 +493,12 @@ def main():
                        **({"options": a.opt} if a.opt else {}),
                        "streams": S, "solves_per_simd": 2 if (S > 1 and not user_variant) else "as set by --opt" if user_variant
                        else 1, "issue_order": "longest first (measured in a warm-up launch of the identical batch)"
-                       if a.sort_by_cost else "batches handed over as drawn; inside a launch the library issues the solves by "
-                       "descending expected cost, a model of the descriptors alone (csrc/launch_order.hpp)",
+                       if a.sort_by_cost else "as drawn: batches handed over as drawn and issued in that order (round 3's "
+                       "device-side ordering by a cost model is gone: it bought 1.6 %)",
                        "as_drawn": not a.sort_by_cost},
             "single_stream": None if single is None else {
                 **region(*single), "note": "the same K steps back to back on one HIP stream, as drawn, one solve per SIMD "
                                            "(every launch alone on the device), measured in this run"},
-            "as_given": None if given_leg is None else {
-                **region(*given_leg), "note": "the timed region with the library's launch ordering off: solves issued in the "
-                                              "order of the descriptor array"},
             "sorted_by_measured_cost": None if sorted_leg is None else {
                 **region(*sorted_leg), "note": "the timed region again with each batch's solves issued longest first, the "
                                                "order measured on the identical batch in a warm-up launch: an upper bound of "

@@ -144,8 +144,6 @@ const char *mtrpl_version(void);
  *   fresh_jac                         accepted and ignored (removed in round 2: the Jacobian is always refreshed at a
  *                                     refactorisation)
  *   max_steps                         a solve that needs more stops early (status 1, tail zero-filled)
- *   order_min_batch                   launches of at least this many solves issue them by descending expected cost
- *                                     (mtrpl_launch_order below; default 256, 0 = as given)
  *   kernel_variant                    std model, nx <= 128: 0 automatic -- the wave kernel (one wavefront per solve)
  *                                     with the elimination blocks stored as fp32 and the re-solve in packed fp32 on
  *                                     an fp64 right-hand side (an approximate inverse applied to the fp64 residual
@@ -208,13 +206,6 @@ int mtrpl_calculate_photoc(mtrpl_ctx *ctx, int64_t n, const double *N, const dou
  * block cyclic-reduction solver for the parity tests. */
 int mtrpl_newton_probe(mtrpl_ctx *ctx, int64_t B, int32_t nx, const double *par, const double *dx,
                        const double *c, const double *y, const double *b, double *x);
-
-/* ---- test entry: the issue order of a launch --------------------------------------- */
-/* perm[0..B): the solve indices in the order a launch of these descriptors would issue them -- by descending
- * expected cost, a linear model in the logarithms of the parameters that decide the step count, evaluated and
- * sorted on the device (csrc/launch_order.hpp; option order_min_batch: launches of at least that many solves are
- * ordered, 0 = never).  Only the issue order depends on it, no result does.  B <= 16384. */
-int mtrpl_launch_order(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *descs, int32_t *perm);
 
 /* ---- test entry: the controller's merged fp32 wave reductions -------------- */
 /* in: [B][4][64] floats (4 per-lane quantities of one wavefront); out: [B][7] = sum of row 0 through the one-sum

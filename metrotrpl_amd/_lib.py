@@ -76,7 +76,6 @@ SIGNATURES = {
     "mtrpl_calculate_photoc": (C.c_int, [_vp, C.c_int64, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double, _dp]),
     "mtrpl_I_moment": (C.c_int, [_vp, C.c_int32, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "mtrpl_newton_probe": (C.c_int, [_vp, C.c_int64, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp]),
-    "mtrpl_launch_order": (C.c_int, [_vp, C.c_int64, _vp, _ip]),
     "mtrpl_reduce_probe": (C.c_int, [_vp, C.c_int64, _vp, _vp]),
     "mtrpl_make_I_table": (C.c_int, [_vp, C.c_int32, _dp, _dp, _dp]),
     "mtrpl_irf_conv_len": (C.c_int64, [C.c_double, C.c_double]),

@@ -406,13 +406,13 @@ __global__ __launch_bounds__(64 * W) void solve_kernel_team(const mtrpl_solve_de
                                                              const double *__restrict__ tsteps,
                                                              double *__restrict__ out, int32_t *__restrict__ status,
                                                              int32_t *__restrict__ stats, int64_t B, SolveTuning tune,
-                                                             void *__restrict__ gblk, const int32_t *__restrict__ perm)
+                                                             void *__restrict__ gblk)
 {
     using BK = TeamBackend<T_, W, TRAPS, GBLK, BF32>;
     using row_t = typename BK::row_t;
     const unsigned long long clk0_ = __builtin_amdgcn_s_memtime();
     if ((int64_t)blockIdx.x >= B) return;
-    const int64_t sidx = perm ? perm[blockIdx.x] : blockIdx.x;  // launch_order.hpp
+    const int64_t sidx = blockIdx.x;
     __shared__ row_t xbuf_lds[BK::kXbufRows];
     __shared__ T_ rbuf_lds[BK::kRbufVals];
     __shared__ row_t blk_lds[GBLK ? 1 : BK::kBlkRows];

@@ -393,12 +393,11 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_wave(const mtrpl_solve_des
                                                             const double *__restrict__ ini,
                                                             const double *__restrict__ tsteps,
                                                             double *__restrict__ out, int32_t *__restrict__ status,
-                                                            int32_t *__restrict__ stats, int64_t B, SolveTuning tune,
-                                                            const int32_t *__restrict__ perm)
+                                                            int32_t *__restrict__ stats, int64_t B, SolveTuning tune)
 {
     const unsigned long long clk0_ = __builtin_amdgcn_s_memtime();
     if ((int64_t)blockIdx.x >= B) return;
-    const int64_t sidx = perm ? perm[blockIdx.x] : blockIdx.x;  // launch_order.hpp
+    const int64_t sidx = blockIdx.x;
     __shared__ double2 fac_lds[kFactorLdsBytes / 16];
     WaveBackend bk(threadIdx.x & 63, fac_lds);
     if (CT)
@@ -412,12 +411,11 @@ __global__ __launch_bounds__(64, 1) void solve_kernel_wave(const mtrpl_solve_des
 template <bool CT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void solve_kernel_wave2(
     const mtrpl_solve_desc *__restrict__ descs, const double *__restrict__ ini, const double *__restrict__ tsteps,
-    double *__restrict__ out, int32_t *__restrict__ status, int32_t *__restrict__ stats, int64_t B, SolveTuning tune,
-    const int32_t *__restrict__ perm)
+    double *__restrict__ out, int32_t *__restrict__ status, int32_t *__restrict__ stats, int64_t B, SolveTuning tune)
 {
     const unsigned long long clk0_ = __builtin_amdgcn_s_memtime();
     if ((int64_t)blockIdx.x >= B) return;
-    const int64_t sidx = perm ? perm[blockIdx.x] : blockIdx.x;  // launch_order.hpp
+    const int64_t sidx = blockIdx.x;
     __shared__ float4 fac_lds[kFactorLdsBytesF32 / 16];
     WaveBackendT<true> bk(threadIdx.x & 63, fac_lds);
     if (CT)
@@ -432,12 +430,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 template <bool CT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void solve_kernel_wave1(
     const mtrpl_solve_desc *__restrict__ descs, const double *__restrict__ ini, const double *__restrict__ tsteps,
-    double *__restrict__ out, int32_t *__restrict__ status, int32_t *__restrict__ stats, int64_t B, SolveTuning tune,
-    const int32_t *__restrict__ perm)
+    double *__restrict__ out, int32_t *__restrict__ status, int32_t *__restrict__ stats, int64_t B, SolveTuning tune)
 {
     const unsigned long long clk0_ = __builtin_amdgcn_s_memtime();
     if ((int64_t)blockIdx.x >= B) return;
-    const int64_t sidx = perm ? perm[blockIdx.x] : blockIdx.x;  // launch_order.hpp
+    const int64_t sidx = blockIdx.x;
     __shared__ float4 fac_lds[kFactorLdsBytesF32 / 16];
     WaveBackendT<true> bk(threadIdx.x & 63, fac_lds);
     if (CT)

@@ -56,9 +56,23 @@ __device__ inline T bulk_recomb(const ParT<T> &p, T N, T P, T NP)
     return ((p.Cn * N + p.Cp * P) + p.ks + frcp1((p.tn * P) + (p.tp * N))) * NP;
 }
 // signal density of one node: ks (N P - n0 p0) (forward_solver.py:228-236,:267-269) or
-// q_C (mu_n (N-n0) + mu_p (P-p0)) (:239-247,:272-274)
+// q_C (mu_n (N-n0) + mu_p (P-p0)) (:239-247,:272-274).
+// The photoconductivity is emitted from the ELECTRON excess: sum_i (P_i - p0) = sum_i (N_i - n0) [+ sum_i Ntrap_i] is an
+// exact invariant of the model (both carriers lose the same recombination, the surface terms enter Jn and Jp with
+// opposite signs, :346-352, :366-370, :410-416, and solve() starts from dP = dN, :120-121, :133), so over the grid
+// q (mu_n (N-n0) + mu_p (P-p0)) and q ((mu_n + mu_p)(N-n0) + mu_p Ntrap) have the same sum -- but P - p0 is a difference
+// of nearly equal numbers once the excess has fallen below the doping (p0 / dP = 1e5 six decades into a TRTS trace:
+// an error of 2.5e-11 of P is 2.7e-6 of the signal, measured on the held-out set), N - n0 is not.
 template <class T>
-__device__ inline T signal_density(const ParT<T> &p, int meas, T N, T P)
+__device__ inline T signal_density(const ParT<T> &p, int meas, T N, T P, T Ntrap)
+{
+    const T dN = N - p.n0;
+    return (meas == MTRPL_MEAS_TRPL) ? p.ks * (N * P - p.n0p0) : (T)kQC * (p.mun * dN + p.mup * (dN + Ntrap));
+}
+// ... and literally as the reference writes it: for the zeroed state behind an early stop (:168), which is not a
+// state of the model
+template <class T>
+__device__ inline T signal_density_literal(const ParT<T> &p, int meas, T N, T P)
 {
     return (meas == MTRPL_MEAS_TRPL) ? p.ks * (N * P - p.n0p0) : (T)kQC * (p.mun * (N - p.n0) + p.mup * (P - p.p0));
 }

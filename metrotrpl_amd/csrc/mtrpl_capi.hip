@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -14,7 +15,6 @@
 #include "irf_kernels.hpp"
 #include "backend_wave.hpp"
 #include "backend_team.hpp"
-#include "launch_order.hpp"
 
 using namespace mtrpl;
 
@@ -41,7 +41,9 @@ struct mtrpl_ctx {
     std::vector<int32_t> irf_nk;
     std::vector<int64_t> irf_off;
     std::vector<double> irf_dt;
-    std::vector<Slab> slabs;
+    // (deques: a Slab* handed out stays valid when a later take_slab of the same call appends to the pool)
+    std::deque<Slab> slabs;        // elimination-block slabs / likelihood work spaces, sized by the launch
+    std::vector<Slab> retired;     // outgrown slabs: freed when the context goes (hipFree would stall every stream)
     // grow-only device scratch of the blocking host-pointer entry points (no hipMalloc/hipFree per call)
     static constexpr int kScratch = 8;
     void *scratch[kScratch] = {};
@@ -50,8 +52,6 @@ struct mtrpl_ctx {
     int precision = 64;      // 64: fp64 (the product); 32: the fp32 build of the team kernel (precision sweep only)
     size_t like_lds_attr = 64 * 1024;  // dynamic-LDS limit the likelihood kernel has been raised to
     unsigned long long call_id = 0;
-    int order_min_batch = 256;  // launches of at least this many solves issue them by descending expected cost
-                                // (launch_order.hpp; 0: as given).  Only the issue order: results do not depend on it
     int two_per_simd_min_batch = 1025;  // kernel_variant 0: launches of at least this many std / nx <= 128 solves use
                                         // the two-solves-per-SIMD build of the wave kernel (more than one solve per
                                         // SIMD anyway), smaller ones the one-per-SIMD build: same results
@@ -283,12 +283,15 @@ int check_descs(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d, int64_t n_
 }
 
 // a slab of at least `need` bytes that no in-flight launch on another stream is using.  The pool holds at most
-// one idle slab that is too small: growing replaces the smallest idle one instead of adding to it, so that a
-// sequence of launches of varying size does not accumulate stale slabs.
-int take_slab(mtrpl_ctx *ctx, size_t need, hipStream_t s, Slab **out)
+// one idle slab that is too small: growing REPLACES the smallest idle one instead of adding to it, so that a
+// sequence of launches of varying size does not accumulate stale slabs.  The outgrown block is not freed here --
+// hipFree synchronises the whole device, i.e. stalls every other stream's launches -- but parked in ctx->retired
+// (freed with the context, or here once more than kRetiredMax bytes are parked).
+constexpr size_t kRetiredMax = (size_t)2 << 30;
+int take_slab(mtrpl_ctx *ctx, std::deque<Slab> &pool, size_t need, hipStream_t s, Slab **out)
 {
     Slab *pick = nullptr, *small = nullptr;
-    for (Slab &sl : ctx->slabs) {
+    for (Slab &sl : pool) {
         if (sl.taken_in == ctx->call_id) continue;  // handed out earlier in this very call
         bool free_ = sl.stream == s;
         if (!free_) {
@@ -305,13 +308,18 @@ int take_slab(mtrpl_ctx *ctx, size_t need, hipStream_t s, Slab **out)
     }
     if (!pick) {
         void *p = nullptr;
-        if (small) {  // idle (or ordered before us on this stream) and too small: hipFree waits for the device
-            (void)hipFree(small->p);
-            small->p = nullptr;
-            small->bytes = 0;
-        }
         HIP_TRY(ctx, hipMalloc(&p, need));
-        if (small) {
+        if (small) {  // idle (or ordered before us on this stream) and too small
+            Slab old;
+            old.p = small->p;
+            old.bytes = small->bytes;
+            ctx->retired.push_back(old);
+            size_t parked = 0;
+            for (const Slab &r : ctx->retired) parked += r.bytes;
+            if (parked > kRetiredMax) {
+                for (Slab &r : ctx->retired) (void)hipFree(r.p);
+                ctx->retired.clear();
+            }
             small->p = p;
             small->bytes = need;
             pick = small;
@@ -323,8 +331,8 @@ int take_slab(mtrpl_ctx *ctx, size_t need, hipStream_t s, Slab **out)
                 (void)hipFree(sl.p);
                 return bad(ctx, MTRPL_ERR_DEVICE, "hipEventCreate failed");
             }
-            ctx->slabs.push_back(sl);
-            pick = &ctx->slabs.back();
+            pool.push_back(sl);
+            pick = &pool.back();
         }
     }
     pick->stream = s;
@@ -332,6 +340,7 @@ int take_slab(mtrpl_ctx *ctx, size_t need, hipStream_t s, Slab **out)
     *out = pick;
     return MTRPL_OK;
 }
+int take_slab(mtrpl_ctx *ctx, size_t need, hipStream_t s, Slab **out) { return take_slab(ctx, ctx->slabs, need, s, out); }
 // behind the launch that uses the slab: the event its next user on another stream waits for.  If the launch itself
 // failed the slab is handed back at once (stream = nullptr marks "no launch pending": the stale event is complete).
 int seal_slab(mtrpl_ctx *ctx, Slab *sl, hipStream_t s, bool launched)
@@ -344,22 +353,22 @@ int seal_slab(mtrpl_ctx *ctx, Slab *sl, hipStream_t s, bool launched)
 template <class T, int W, bool TRAPS, bool GBLK, bool BF32 = false>
 void launch_team(hipStream_t s, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
                  const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats,
-                 const SolveTuning &tune, void *gblk, const int32_t *perm)
+                 const SolveTuning &tune, void *gblk)
 {
     hipLaunchKernelGGL((solve_kernel_team<T, W, TRAPS, GBLK, BF32>), dim3((unsigned)B), dim3(64 * W), 0, s, d_descs, d_ini,
-                       d_tsteps, d_out, d_status, d_stats, B, tune, gblk, perm);
+                       d_tsteps, d_out, d_status, d_stats, B, tune, gblk);
 }
 template <class T>
 int launch_team_any(mtrpl_ctx *ctx, hipStream_t s, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
                     const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats, int32_t max_nx,
-                    bool traps, const int32_t *perm)
+                    bool traps)
 {
     // fp64 solves store their elimination blocks as fp32 (half the LDS: twice the workgroups per CU at W = 2)
     constexpr bool kF32 = sizeof(T) == 8;
 #define MTRPL_TEAM(W_, G_, P_)                                                                                       \
     do {                                                                                                             \
-        if (traps) launch_team<T, W_, true, G_, kF32>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, P_, perm); \
-        else launch_team<T, W_, false, G_, kF32>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, P_, perm);      \
+        if (traps) launch_team<T, W_, true, G_, kF32>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, P_); \
+        else launch_team<T, W_, false, G_, kF32>(s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, ctx->tune, P_);      \
     } while (0)
     if (max_nx <= 128) MTRPL_TEAM(1, false, nullptr);
     else if (max_nx <= 256) MTRPL_TEAM(2, false, nullptr);
@@ -384,26 +393,6 @@ int launch_team_any(mtrpl_ctx *ctx, hipStream_t s, int64_t B, const mtrpl_solve_
         }
     }
 #undef MTRPL_TEAM
-    return MTRPL_OK;
-}
-
-// the issue order of a launch (launch_order.hpp): a permutation in a slab of its own, sorted on the device behind
-// whatever the stream holds; nullptr = as given
-int make_order(mtrpl_ctx *ctx, hipStream_t s, int64_t B, const mtrpl_solve_desc *d_descs, const int32_t **perm, Slab **slab)
-{
-    *perm = nullptr;
-    *slab = nullptr;
-    if (ctx->order_min_batch <= 0 || B < ctx->order_min_batch || B > kOrderMax) return MTRPL_OK;
-    Slab *sl = nullptr;
-    const int rc = take_slab(ctx, (sizeof(int32_t) + sizeof(float)) * (size_t)B, s, &sl);
-    if (rc != MTRPL_OK) return rc;
-    int32_t *d_perm = static_cast<int32_t *>(sl->p);
-    float *d_keys = reinterpret_cast<float *>(d_perm + B);
-    const unsigned nwg = (unsigned)((B + 63) / 64);
-    hipLaunchKernelGGL(cost_key_kernel, dim3(nwg), dim3(64), 0, s, d_descs, (int)B, d_keys);
-    hipLaunchKernelGGL(cost_rank_kernel, dim3(nwg), dim3(64), 0, s, d_keys, (int)B, d_perm);
-    *perm = static_cast<const int32_t *>(sl->p);
-    *slab = sl;
     return MTRPL_OK;
 }
 
@@ -443,6 +432,7 @@ int mtrpl_ctx_destroy(mtrpl_ctx *ctx)
         if (sl.p) (void)hipFree(sl.p);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    for (Slab &sl : ctx->retired) (void)hipFree(sl.p);
     for (int k = 0; k < mtrpl_ctx::kScratch; ++k)
         if (ctx->scratch[k]) (void)hipFree(ctx->scratch[k]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -468,6 +458,7 @@ const OptD kOptD[] = {
     {"early_frac", &SolveTuning::early_frac}, {"hmax_deep", &SolveTuning::hmax_deep},
     {"hmax_scale", &SolveTuning::hmax_scale}, {"tail_frac", &SolveTuning::tail_frac}, {"tail_factor", &SolveTuning::tail_factor},
     {"far_frac", &SolveTuning::far_frac}, {"far_factor", &SolveTuning::far_factor}, {"deep_factor", &SolveTuning::deep_factor},
+    {"shape_factor", &SolveTuning::shape_factor}, {"fun_weight", &SolveTuning::fun_weight},
 };
 const OptI kOptI[] = {
     {"max_steps", &SolveTuning::max_steps}, {"rate_max_age", &SolveTuning::rate_max_age},
@@ -502,8 +493,6 @@ int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value)
         // removed in round 2 (the Jacobian is always refreshed at a refactorisation): accepted and ignored
     } else if (k == "two_per_simd_min_batch") {
         ctx->two_per_simd_min_batch = (int)value;
-    } else if (k == "order_min_batch") {
-        ctx->order_min_batch = (int)value;
     } else if (k == "precision") {
         if (value != 32 && value != 64) return bad(ctx, MTRPL_ERR_BAD_ARG, "precision must be 32 or 64");
         ctx->precision = (int)value;
@@ -523,7 +512,6 @@ int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value)
         if (k == o.key) { *value = ctx->tune.*(o.m); return MTRPL_OK; }
     if (k == "kernel_variant") *value = ctx->kernel_variant;
     else if (k == "two_per_simd_min_batch") *value = ctx->two_per_simd_min_batch;
-    else if (k == "order_min_batch") *value = ctx->order_min_batch;
     else if (k == "precision") *value = ctx->precision;
     else if (k == "fresh_jac") *value = 0.0;  // accepted and ignored (set_option)
     else return MTRPL_ERR_BAD_ARG;
@@ -543,20 +531,9 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
     ctx->call_id++;
     hipStream_t s = (hipStream_t)stream;  // exactly the caller's stream (NULL = the default stream)
     const bool traps = model == MTRPL_MODEL_TRAPS;
-    const int32_t *perm = nullptr;
-    Slab *order_slab = nullptr;
-    {
-        const int rc = make_order(ctx, s, B, d_descs, &perm, &order_slab);
-        if (rc != MTRPL_OK) return rc;
-    }
-    // the permutation's slab is free again once the solve kernel behind it has run
-    struct SealOrder {
-        mtrpl_ctx *c; Slab *sl; hipStream_t s;
-        ~SealOrder() { if (sl) (void)hipEventRecord(sl->done, s); }
-    } seal_order{ctx, order_slab, s};
     if (ctx->precision == 32) {
         if (traps) return bad(ctx, MTRPL_ERR_UNSUPPORTED, "the fp32 build covers the std model only");
-        const int rc = launch_team_any<float>(ctx, s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, max_nx, false, perm);
+        const int rc = launch_team_any<float>(ctx, s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, max_nx, false);
         if (rc != MTRPL_OK) return rc;
         HIP_TRY(ctx, hipGetLastError());
         return MTRPL_OK;
@@ -575,12 +552,12 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
 #define MTRPL_WAVE(KERNEL)                                                                                            \
     do {                                                                                                              \
         if (ct) hipLaunchKernelGGL(KERNEL<true>, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,  \
-                                   d_status, d_stats, B, ctx->tune, perm);                                            \
+                                   d_status, d_stats, B, ctx->tune);                                                  \
         else hipLaunchKernelGGL(KERNEL<false>, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,    \
-                                d_status, d_stats, B, ctx->tune, perm);                                               \
+                                d_status, d_stats, B, ctx->tune);                                                     \
     } while (0)
     if (traps || max_nx > 128 || variant == 1) {
-        const int rc = launch_team_any<double>(ctx, s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, max_nx, traps, perm);
+        const int rc = launch_team_any<double>(ctx, s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, max_nx, traps);
         if (rc != MTRPL_OK) return rc;
     } else if (variant == 3) {
         MTRPL_WAVE(solve_kernel_wave2);
@@ -697,32 +674,6 @@ int mtrpl_newton_probe(mtrpl_ctx *ctx, int64_t B, int32_t nx, const double *par,
 #undef MTRPL_NP_ARGS
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(x, dxo.p, sizeof(double) * S * B, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    return MTRPL_OK;
-}
-
-int mtrpl_launch_order(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *descs, int32_t *perm)
-{
-    if (!ctx) return MTRPL_ERR_BAD_ARG;
-    if (B <= 0) return MTRPL_OK;
-    if (!descs || !perm) return bad(ctx, MTRPL_ERR_BAD_ARG, "null pointer");
-    if (B > kOrderMax) return bad(ctx, MTRPL_ERR_UNSUPPORTED, "launches of more than 16384 solves are issued as given");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf dd(ctx, 0);
-    HIP_TRY(ctx, dd.alloc(sizeof(mtrpl_solve_desc) * B));
-    hipStream_t s = ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(dd.p, descs, sizeof(mtrpl_solve_desc) * B, hipMemcpyHostToDevice, s));
-    const int saved = ctx->order_min_batch;
-    ctx->order_min_batch = 1;
-    ctx->call_id++;
-    const int32_t *d_perm = nullptr;
-    Slab *sl = nullptr;
-    const int rc = make_order(ctx, s, B, dd.as<mtrpl_solve_desc>(), &d_perm, &sl);
-    ctx->order_min_batch = saved;
-    if (rc != MTRPL_OK) return rc;
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(perm, d_perm, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipEventRecord(sl->done, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     return MTRPL_OK;
 }
@@ -847,6 +798,11 @@ extern "C" int mtrpl_debug_trace(float *out, int *n)
     hipMemcpyFromSymbol(out, HIP_SYMBOL(mtrpl::g_trace), sizeof(float) * 8 * 8192);
     int zero = 0;
     hipMemcpyToSymbol(HIP_SYMBOL(mtrpl::g_trace_n), &zero, sizeof(int));
+    return 0;
+}
+extern "C" int mtrpl_debug_trace_select(int sidx)
+{
+    hipMemcpyToSymbol(HIP_SYMBOL(mtrpl::g_trace_sel), &sidx, sizeof(int));
     return 0;
 }
 #endif

@@ -55,7 +55,8 @@ namespace mtrpl {
 #ifdef MTRPL_TRACE
 __device__ float g_trace[8 * 8192];
 __device__ int g_trace_n;
-#define TRACE(code, n_iter_, dsm_) do { if (sidx == MTRPL_TRACE && bk.leader() && g_trace_n < 8192) { float *q_ = g_trace + 8 * g_trace_n++; \
+__device__ int g_trace_sel = MTRPL_TRACE;  // the traced solve (mtrpl_debug_trace_select)
+#define TRACE(code, n_iter_, dsm_) do { if (sidx == g_trace_sel && bk.leader() && g_trace_n < 8192) { float *q_ = g_trace + 8 * g_trace_n++; \
     q_[0] = (float)(code); q_[1] = (float)t; q_[2] = (float)h; q_[3] = (float)order; q_[4] = (float)(n_iter_); q_[5] = (float)(dsm_); q_[6] = (float)n_equal; q_[7] = (float)io; } } while (0)
 #else
 #define TRACE(code, n_iter_, dsm_) do { } while (0)
@@ -94,6 +95,10 @@ struct SolveTuning {
     double nq_bias_same, nq_bias_down, nq_bias_up;  // multipliers of the step factors (stode: 1/1.2, 1/1.3, 1/1.4)
     double early_factor;      // > 1: local tolerance x this for steps ending before early_frac * (first sample time)
     double early_frac;
+    double shape_factor;      // > 1: goal-oriented error test (DESIGN.md "error control"): the RMS norm of the local error
+    double fun_weight;        // estimate is allowed shape_factor x the tolerance as long as its MASS component -- the
+                              // signed grid sum of the estimate for N against the grid sum of N, weighted fun_weight --
+                              // stays inside the tolerance itself
 };
 
 // The shipped settings as compile-time constants: a kernel instantiated on this type instead of on the
@@ -106,16 +111,17 @@ struct DefaultTune {
     static constexpr int rate_max_age = 8;
     static constexpr double rate_first_safety = 4.0, e_weight = 3.0;
     static constexpr int honor_hmax = 1;
-    static constexpr double hmax_deep = 1e-11, deep_factor = 1000.0, hmax_scale = 1.0, tail_frac = 1e-4, tail_factor = 0.4, far_frac = 1e-9, far_factor = 3.0, trts_rtol_factor = 0.5, amp_ref = 10.0, amp_post = 0.03, nq_deadband_hi = 1.2;
+    static constexpr double hmax_deep = 1e-11, deep_factor = 1000.0, hmax_scale = 1.0, tail_frac = 1e-4, tail_factor = 1.0, far_frac = 1e-9, far_factor = 3.0, trts_rtol_factor = 0.5, amp_ref = 10.0, amp_post = 0.03, nq_deadband_hi = 1.2;
     static constexpr int nq_rej_memory = 80;
     static constexpr double nq_rej_growth = 1.2, nq_bias_same = 1.0, nq_bias_down = 1.0, nq_bias_up = 1.0;
     static constexpr double early_factor = 10.0, early_frac = 0.5;
+    static constexpr double shape_factor = 30.0, fun_weight = 3.0;
     static SolveTuning make()
     {
         return SolveTuning{rtol_scale, rtol_cap, rtol_floor, rtol_min, rtol_force, atol_rel, atol_rel_np, max_steps,
                            newton_tol, rate_max_age, rate_first_safety, e_weight, honor_hmax, hmax_deep, deep_factor, hmax_scale, tail_frac, tail_factor, far_frac, far_factor, trts_rtol_factor,
                            amp_ref, amp_post, nq_deadband_hi, nq_rej_memory, nq_rej_growth, nq_bias_same, nq_bias_down, nq_bias_up,
-                           early_factor, early_frac};
+                           early_factor, early_frac, shape_factor, fun_weight};
     }
 };
 
@@ -359,7 +365,9 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         // absolute term is tiny; desc.atol (solver units, nm^-3) bounds it from above -- the default 1e-10
         // never does.  The field passes through zero and keeps an absolute floor in the scale of the
         // problem (a tiny one makes every BDF code crawl there, LSODA included).
-        atol = (real)fmin(r_ * tune.atol_rel_np * (double)dNmax, ds.atol);
+        // (never exactly zero: the trapped density of the traps model starts at 0, and 0 / (0 + rtol * 0) in the
+        // norms of the initial step would be NaN for a caller's ATOL = 0)
+        atol = (real)fmax(fmin(r_ * tune.atol_rel_np * (double)dNmax, ds.atol), sizeof(real) == 8 ? 1e-300 : 1e-37);
         atol_E = (real)(r_ * tune.atol_rel * (double)dNmax);
     }
     // the field is a fast slaved variable (dielectric relaxation): its local error is damped, not
@@ -369,9 +377,11 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
     auto is_E = [](int v) { return v >= 2 * R && v < 3 * R; };
     auto rtol_of = [&](int v) { return is_E(v) ? rtol_E : rtol; };
     auto atol_of = [&](int v) { return is_E(v) ? atol_E : atol; };
-    // the same as fp32 weights 1/(atol + rtol |y|) are built from.  Relative to the largest initial density so
-    // that atol (1e-21 nm^-3 and below) and the densities stay far inside the fp32 range.
-    const ctl rtol_f = (ctl)rtol, rtol_E_f = (ctl)rtol_E, atol_f = (ctl)atol, atol_E_f = (ctl)atol_E;
+    // the same as fp32 values: what the weights 1/(atol + rtol |y|) are built from.  Densities (1e-4 ... 1e-22 nm^-3)
+    // and tolerances are far inside the fp32 range; the absolute terms are kept above its smallest normal number,
+    // so that a caller's ATOL = 0 (or 1e-45) next to a component that has gone to zero gives a finite weight and
+    // not 1/0 (the reference's LSODA integrates such a case).
+    const ctl rtol_f = (ctl)rtol, rtol_E_f = (ctl)rtol_E, atol_f = fmaxf((ctl)atol, 1e-37f), atol_E_f = fmaxf((ctl)atol_E, 1e-37f);
     const real early_until = (nt > 1) ? (real)(tune.early_frac * ts[1]) : (real)0;
     const ctl early_mul = (ctl)(1.0 / fmax(tune.early_factor, 1.0));  // norms of an early step are scaled by this
     const ctl tail_mul = (ctl)(1.0 / tune.tail_factor), far_mul = (ctl)(1.0 / tune.far_factor), deep_mul = (ctl)(1.0 / (tune.far_factor * tune.deep_factor)), amp_mul = (ctl)amp_mul_d;
@@ -379,24 +389,25 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                                ? (ctl)tune.newton_tol
                                : (ctl)fmax(10.0 * 2.220446049250313e-16 / (double)rtol, fmin(0.03, sqrt((double)rtol)));
 
+    const bool goal = tune.shape_factor > 1.0;  // goal-oriented error test on
     int n_steps = 0, n_rhs = 0, n_fac = 0, n_bad = 0;  // n_bad: rejected steps | Newton failures << 16
     int st = MTRPL_SOLVE_OK;
 
     // dx-less grid sum of the signal density of one state
-    auto sig_partial = [&](const real (&nn)[R], const real (&pp)[R]) {
+    auto sig_partial = [&](const real (&nn)[R], const real (&pp)[R], const real (&tr)[R]) {
         real s = (real)0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const real v = signal_density(p, meas, nn[r], pp[r]);
+            const real v = TRAPS ? signal_density(p, meas, nn[r], pp[r], tr[r]) : signal_density(p, meas, nn[r], pp[r], (real)0);
             s += (bk.node(r) < L) ? v : (real)0;
         }
         return s;
     };
     {
-        real nn[R], pp[R];
+        real nn[R], pp[R], tr[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { nn[r] = y[r]; pp[r] = y[R + r]; }
-        bk.out_first(sig_partial(nn, pp));
+        for (int r = 0; r < R; ++r) { nn[r] = y[r]; pp[r] = y[R + r]; tr[r] = (real)0; }  // (:133: the traps start empty)
+        bk.out_first(sig_partial(nn, pp, tr));
     }
 
     real z[6][V];
@@ -510,6 +521,8 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         real hv[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) hv[r] = (bk.node(r) < L) ? h : (real)0;
+        // goal-oriented error test (DESIGN.md "error control"): error test value / its RMS part
+        ctl rho = 1.0f;
         MTRPL_STAMP(ph_ctl);
 
         // ---- simplified Newton on acor:  (I - h l0 J) dx = h f(y) - z[1] - acor,  y = z[0] + l0 acor ----
@@ -561,6 +574,16 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                     s4[0] = fmaf(wv, wv, s4[0]);
                     s4[1] = fmaf(av, av, s4[1]);
                 }
+                // goal-oriented test: the SIGNED grid sum of the correction of N (its mass component; padded nodes carry
+                // an exactly zero correction) and the grid sum of the predicted N, in the same reduction as the norms
+                float sfm[2] = {0.0f, 0.0f};
+                if (goal) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        sfm[0] += acf[r];
+                        sfm[1] += (bk.node(r) < L) ? (float)z[0][r] : 0.0f;
+                    }
+                }
                 if (will_select) {
                     // stode: ddn from the last Nordsieck row (after the correction), dup from acor - acor_prev
                     const float elK = (float)nq.elK;
@@ -582,6 +605,15 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                     }
                     MTRPL_STAMP(ph_glue);
                     bk.template reduce_f<4>(s4);
+                    if (goal) bk.template reduce_f<2>(sfm);
+                } else if (goal) {
+                    float g4[4] = {s4[0], s4[1], sfm[0], sfm[1]};
+                    MTRPL_STAMP(ph_glue);
+                    bk.template reduce_f<4>(g4);
+                    s4[0] = g4[0];
+                    s4[1] = g4[1];
+                    sfm[0] = g4[2];
+                    sfm[1] = g4[3];
                 } else {
                     float s2[2] = {s4[0], s4[1]};
                     MTRPL_STAMP(ph_glue);
@@ -613,6 +645,13 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                 if (negligible || (rate_ok && rate < 1.0f && rate * dn < newton_tol * (1.0f - rate))) {
                     converged = 1;
                     dsm = nscale * __builtin_amdgcn_sqrtf(s4[1] * inv_S) * (ctl)nq.inv_t2;
+                    if (goal) {
+                        // RMS norm against shape_factor x the tolerance, mass component against the tolerance / fun_weight
+                        const ctl dfun = nscale * (ctl)tune.fun_weight * fabsf(sfm[0]) * __builtin_amdgcn_rcpf(rtol_f * sfm[1]) * (ctl)nq.inv_t2;
+                        const ctl dboth = fmaxf(dsm * (ctl)(1.0 / tune.shape_factor), dfun);
+                        rho = (dsm > 0.0f) ? dboth * __builtin_amdgcn_rcpf(dsm) : 1.0f;
+                        dsm = dboth;
+                    }
                     ssel0 = s4[2];
                     ssel1 = s4[3];
                     break;
@@ -636,7 +675,8 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         if (!converged || dsm > 1.0f) {
             // Newton failed with fresh factors (halve the step) or the error test failed (stode's factor)
             TRACE(converged ? 1 : 2, n_iter, dsm);
-            n_bad += converged ? 1 : (1 << 16);
+            // rejected steps in the low half (saturating), Newton failures in the high half
+            n_bad += converged ? (((n_bad & 0xffff) != 0xffff) ? 1 : 0) : (1 << 16);
             fails++;
             if (converged) since_rej = 0;
             facz = converged ? (real)fmaxf(0.2f, safety * pow_ctl(dsm, -nq.inv_qp1)) : (real)0.5;
@@ -666,11 +706,12 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                 const real ih = frcp(h);
                 do {
                     const real s_ = (tq_next - t) * ih;
-                    real nn[R], pp[R];
+                    real nn[R], pp[R], tr[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         nn[r] = z[5][r];
                         pp[r] = z[5][R + r];
+                        tr[r] = TRAPS ? z[5][(TRAPS ? 3 : 0) * R + r] : (real)0;
                     }
 #pragma unroll
                     for (int j = 4; j >= 0; --j)
@@ -678,8 +719,9 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                         for (int r = 0; r < R; ++r) {
                             nn[r] = nn[r] * s_ + z[j][r];
                             pp[r] = pp[r] * s_ + z[j][R + r];
+                            if (TRAPS) tr[r] = tr[r] * s_ + z[j][(TRAPS ? 3 : 0) * R + r];
                         }
-                    bk.out_sample(io, sig_partial(nn, pp));
+                    bk.out_sample(io, sig_partial(nn, pp, tr));
                     io++;
                     if (io - io0 >= 64) {
                         io0 = io;
@@ -695,8 +737,10 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                 // sequence on lanes 0..2 (nothing here is lane-uniform until the three results are read back).
                 ctl fm, f0, fp;
                 {
-                    const ctl ddn = nscale * (ctl)nq.inv_t1 * __builtin_amdgcn_sqrtf(ssel0 * inv_S);
-                    const ctl dup = nscale * (ctl)nq.inv_t3 * __builtin_amdgcn_sqrtf(ssel1 * inv_S);
+                    // (goal-oriented test: the neighbouring orders' estimates are taken to split into shape and mass
+                    // like this order's)
+                    const ctl ddn = rho * nscale * (ctl)nq.inv_t1 * __builtin_amdgcn_sqrtf(ssel0 * inv_S);
+                    const ctl dup = rho * nscale * (ctl)nq.inv_t3 * __builtin_amdgcn_sqrtf(ssel1 * inv_S);
                     ctl x = (lane64 == 0) ? ddn : ((lane64 == 1) ? dsm : dup);
                     const ctl e = (lane64 == 0) ? nq.nik0 : ((lane64 == 1) ? nq.nik1 : nq.nik2);
                     x = fminf(fmaxf(x, 1e-30f), 1e30f);
@@ -750,10 +794,9 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
 
     if (st != MTRPL_SOLVE_OK) {
         // forward_solver.py:168: samples after the last solved time come from a zeroed state
-        real zn[R], zp[R];
+        real zsig = (real)0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) { zn[r] = (real)0; zp[r] = (real)0; }
-        const real zsig = sig_partial(zn, zp);
+        for (int r = 0; r < R; ++r) zsig += (bk.node(r) < L) ? signal_density_literal(p, meas, (real)0, (real)0) : (real)0;
         for (; io < nt; ++io) bk.out_sample(io, zsig);
     } else if (tol_clamped) {
         st = MTRPL_SOLVE_OK_TOL_CLAMPED;

@@ -250,12 +250,8 @@ class LikelihoodEngine:
         n_parts = len(cuts) - 1
         while len(self._side) < n_parts - 1:
             self._side.append(torch.cuda.Stream(device=self.dev))
-        # the solves of this launch already stand in the order of their MEASURED cost: keep the library from
-        # re-ordering them by its a-priori model (launch_order.hpp)
-        keep_order = self._order is not None
-        if keep_order:
-            prev_min = self.ctx.get_option("order_min_batch")
-            self.ctx.set_option("order_min_batch", 0)
+        # (the library issues the solves of a launch in the order of the descriptor array: the measured-cost order
+        # this engine packed them in is the order they run in)
         fork = None
         if n_parts > 1:
             fork = torch.cuda.Event()
@@ -292,8 +288,6 @@ class LikelihoodEngine:
                 joins.append(ev)
         for ev in joins:
             main.wait_event(ev)
-        if keep_order:
-            self.ctx.set_option("order_min_batch", prev_min)
         self._prev_order = self._order  # which solve sat where, for the cost read-back of the next launch
         if self._order is not None:
             # the residencies of this launch, for the ordering of the next: copied to pinned memory behind the

@@ -137,6 +137,13 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     stats = eng.d_stats.cpu().numpy().reshape(-1, 8)
+    # the slowest solve of a rank's last launch is what that rank's iteration waits for: one figure per rank
+    steps_rank = [int(stats[:, 0].max())]
+    if getattr(a, "use_dist", world > 1):
+        mine = torch.tensor(steps_rank, dtype=torch.int64, device=dev)
+        every = torch.zeros(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(every, mine)
+        steps_rank = [int(v) for v in every.cpu()]
     line = {
         "metric": "mcmc_proposals_per_sec", "value": n_chains * a.steps / dt, "unit": "proposals/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
@@ -151,7 +158,8 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
                    "forward_solves_per_sec": n_chains * 6 * a.steps / dt, "accepted_moves": n_acc,
                    "swap_accept_rate": float(ens.swap_accepts.sum() / max(1, ens.swap_attempts.sum())),
                    "mean_integrator_steps_rank0": float(stats[:, 0].mean()),
-                   "max_integrator_steps_rank0": int(stats[:, 0].max())},
+                   "max_integrator_steps_rank0": int(stats[:, 0].max()),
+                   "max_integrator_steps_per_rank": steps_rank},
     }
     if rank == 0:
         # roofline of the dominant kernel (the forward solve) from the HIP events recorded around every

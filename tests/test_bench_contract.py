@@ -100,3 +100,21 @@ def test_without_a_gpu_bench_fails_loudly_and_prints_no_line():
     assert r.returncode == 3, (r.returncode, r.stderr[-300:])
     assert r.stdout == ""
     assert "no GPU visible" in r.stderr
+
+
+def test_gpus_2_without_a_launcher_starts_nothing_on_a_gpu_less_box():
+    """`python bench.py --gpus N` (WORLD_SIZE unset) starts its N ranks itself as a child torch.distributed.run -- before
+    this process makes any GPU call, never an exec.  Without N visible GPUs nothing is started: exit code 3, the reason
+    on stderr, nothing on stdout (the bare command used to exit 2 with 'launch with torch.distributed.run')."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("needs a machine with fewer than two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, cwd=REPO, timeout=300, env=env)
+    assert r.returncode == 3, (r.returncode, r.stderr[-300:])
+    assert r.stdout == ""
+    assert "--gpus 2" in r.stderr and "GPU(s) visible" in r.stderr

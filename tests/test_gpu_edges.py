@@ -137,36 +137,16 @@ def test_odd_and_tiny_grids_against_the_oracle():
             assert err < 1e-6, (nx, thick, meas, err)
 
 
-def test_launch_order_is_a_permutation_by_cost_and_changes_no_result():
-    """csrc/launch_order.hpp: a launch issues its solves by descending expected cost (a model of the descriptors alone,
-    sorted on the device).  The order is a permutation, it puts the solves that turn out expensive first (rank
-    correlation with the measured step counts), and no result depends on it -- bit for bit."""
-    import ctypes as C
-    from scipy.stats import spearmanr
-    from metrotrpl_amd import batch, workloads as W
+def test_the_library_issues_a_launch_as_given():
+    """Round 3's device-side issue ordering (a cost model of the descriptors, two kernels in front of every launch) is
+    gone -- it cost more than it bought.  A launch runs its solves in the order of the descriptor array; a
+    caller who knows better (LikelihoodEngine: the cost measured one Metropolis iteration earlier) orders the array."""
     L, ctx = _ctx()
-    B = 700  # not a power of two
-    c = W.config2(B)
-    d, ini = batch.build_batch(c["states"], W.indexes(), W.units(), c["iniPar"], c["thickness"], c["nx"], len(c["tSteps"]))
-    perm = np.full(B, -1, dtype=np.int32)
-    ctx.check(L.lib().mtrpl_launch_order(ctx.handle, B, d.ctypes.data_as(C.c_void_p), L.iptr(perm)))
-    assert sorted(perm.tolist()) == list(range(B))
-    assert ctx.get_option("order_min_batch") == 256
-    sig, status, stats = batch.solve_batch(c["states"], W.indexes(), W.units(), c["iniPar"], c["thickness"], c["nx"],
-                                           c["tSteps"], return_stats=True)
-    position = np.empty(B)
-    position[perm] = np.arange(B)
-    rho = spearmanr(-position, stats[:, 0]).correlation
-    print(f"rank correlation of the issue order with the measured step counts: {rho:.2f}")
-    assert rho > 0.7
-    ctx.set_option("order_min_batch", 0)
-    try:
-        sig0, status0, stats0 = batch.solve_batch(c["states"], W.indexes(), W.units(), c["iniPar"], c["thickness"], c["nx"],
-                                                  c["tSteps"], return_stats=True)
-    finally:
-        ctx.set_option("order_min_batch", 256)
-    np.testing.assert_array_equal(sig, sig0)
-    np.testing.assert_array_equal(stats[:, :7], stats0[:, :7])
+    with pytest.raises(Exception):
+        ctx.get_option("order_min_batch")
+    with pytest.raises(Exception):
+        ctx.set_option("order_min_batch", 0)
+    assert not hasattr(L.lib(), "mtrpl_launch_order")
 
 
 def test_every_option_the_header_documents_exists():

@@ -224,6 +224,19 @@ def test_mixed_trpl_trts_likelihood_at_nx512(team):
     table = eng.eval(team["mixed_state"][None, :], team["mixed_T"])[0]
     ref = team["mixed_table"]
     assert ref.shape == table.shape == (2, 4) and np.all(np.isfinite(ref)) and np.all(ref < 0)
-    # atol as in test_gpu_likelihood: n (d log10)^2 with d log10 ~ 4e-8 (1e-7 relative on the signal); the TRTS row is a
-    # near-perfect fit (ll ~ 1e-4) and sits next to it
-    np.testing.assert_allclose(table, ref, rtol=1e-6, atol=1e-9 * np.max(np.abs(ref)) + 1e-10)
+    # The data of this fixture are the traces of a NEIGHBOURING state: err = log10(sig) - vals is small (0.02 ... 0.06),
+    # so a relative error eps of the simulated signal moves ll = -sum err^2 / (sigma^2 T + 2 u^2) by 2 eps / (ln 10 |err|)
+    # relatively -- about 20 eps.  The gate is therefore the SIGNAL gate of SURVEY 8d (1e-6, here held at 2e-7) carried
+    # through to first order, sample by sample: |d ll| <= sum 2 |err_i| (eps / ln 10) / (sigma^2 T + 2 u_i^2).  (Round 3
+    # asked for 1e-6 on ll itself, i.e. 5e-8 on the signal, tighter than the oracle of this fixture -- LSODA at
+    # rtol 1e-10 -- is converged.)
+    nt = len(t)
+    sig = eng.d_sig.cpu().numpy().reshape(2, nt)
+    eps = 2e-7
+    for m in range(2):
+        err = np.log10(sig[m]) - team["mixed_vals"][m]
+        sg2 = float(team["mixed_sigma"][m]) ** 2
+        bound = np.array([np.sum(2 * np.abs(err) * (eps / np.log(10)) / (sg2 * T_ + 2 * team["mixed_uncs"][m] ** 2))
+                          for T_ in team["mixed_T"]])
+        assert np.all(np.abs(table[m] - ref[m]) <= bound + 1e-12), (m, np.abs(table[m] - ref[m]) / bound)
+        assert np.all(bound < 1e-5 * np.abs(ref[m]))  # the bound is a tight one: a few 1e-6 of ll

@@ -110,3 +110,31 @@ def test_deep_zone_relaxation_touches_no_sample_above_it():
     assert n_deep >= 10, n_deep  # the fixture does reach down there
     assert stats0[:, 0].sum() < stats1[:, 0].sum()
     print(f"{n_deep} of {len(sel)} traces reach the zone; steps {stats1[:, 0].mean():.0f} -> {stats0[:, 0].mean():.0f}")
+
+
+def test_atol_zero_is_integrated_like_the_reference_does():
+    """ATOL = 0 (or a denormal) is legal for the reference's LSODA.  The fp32 error weights 1/(atol + rtol |y|) of
+    the controller must stay finite next to a component that is (or has gone to) zero -- ADVICE r3: they flushed to
+    1/0, every attempt was booked as a Newton failure and the solve stopped early with a zero-filled tail."""
+    from metrotrpl_amd import batch, workloads as W
+    z = np.load(os.path.join(G, "tail_decades.npz"))
+    sel = np.arange(0, 16)
+    ref = z["sig"][sel]
+    base, st0, stats0 = _solve(z, sel)
+    for atol in (0.0, 1e-45):
+        sig, st, stats = _solve(z, sel, atol=atol)
+        assert np.all(st == 0), (atol, st)
+        assert np.all(np.isfinite(sig)) and np.all(stats[:, 5] == 0)  # no Newton failure
+        assert _err(sig, ref, 0, 9) <= 1e-6
+        assert stats[:, 0].max() < 3 * stats0[:, 0].max()
+    # the traps model starts from a trapped density of exactly zero
+    team = np.load(os.path.join(G, "team_cases.npz"))
+    idx = {n: i for i, n in enumerate(str(team["traps_names"]).split(","))}
+    t0, s0, _ = batch.solve_batch(team["traps_states"][:2], idx, team["traps_units"], team["traps_ini"][:2],
+                                  team["traps_thickness"][:2], 128, team["traps_t"], model="traps", return_stats=True)
+    t1, s1, x1 = batch.solve_batch(team["traps_states"][:2], idx, team["traps_units"], team["traps_ini"][:2],
+                                   team["traps_thickness"][:2], 128, team["traps_t"], model="traps", ATOL=0.0,
+                                   return_stats=True)
+    assert np.all(s0 == 0) and np.all(s1 == 0) and np.all(x1[:, 5] == 0)
+    m = np.abs(t0) >= 1e-4 * np.abs(t0[:, :1])
+    assert np.max(np.abs(t1 - t0)[m] / np.abs(t0)[m]) < 1e-6

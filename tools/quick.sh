@@ -9,7 +9,7 @@ import json
 d=json.load(open("gpurun_out/${T}_bench.json"))
 c=d["config"]
 print("as-drawn x3 %.0f/s %.3f ms | steps %.1f rhs %.1f max %d" % (d["value"], d["ms_per_step"], c["mean_integrator_steps"], c["mean_rhs_evals"], c["max_integrator_steps"]))
-for k in ("single_stream","as_given","sorted_by_measured_cost","fp64_linear_algebra"):
+for k in ("single_stream","sorted_by_measured_cost","fp64_linear_algebra"):
     if d.get(k): print("%-24s %.0f/s %.3f ms ok=%s" % (k, d[k]["solves_per_sec"], d[k]["ms_per_step"], d[k]["all_solves_ok"]))
 a=d["accuracy"]; print("acc", ["%.2e"%x for x in a["max_rel_err_per_decade_0_to_8"]], a["all_ok"])
 PY
