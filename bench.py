@@ -26,7 +26,9 @@ is gone.)  Measured in the same run and reported beside it:
                            MEASURED on the identical batch in a warm-up launch -- knowledge a
                            first-time caller does not have: an upper bound of what ordering can
                            buy, not the headline
-  fp64_linear_algebra      single_stream on kernel_variant 2 (fp64 blocks, fp64 re-solve)
+  fp64_linear_algebra      single_stream on kernel_variant 2 (fp64 blocks, fp64 re-solve); .streams: the timed
+                           region itself on that kernel
+  one_launch               one launch of 2048 / 4096 solves at a time: what a caller without streams gets
   pt                       BASELINE's second metric: MCMC proposals/s of the config-3 (64 chains)
                            and config-4-on-one-GPU (512 chains) parallel-tempering ensembles
 
@@ -437,6 +439,51 @@ def main():
         torch.cuda.synchronize()
         sorted_leg = timed(S)
         cur["descs"] = d_descs_drawn
+    # ---- (4) the timed region on the all-fp64 linear algebra (kernel_variant 2: one solve per SIMD, 34 KB of LDS) ----
+    fp64la_streams = None
+    if not a.quick and S > 1 and not user_variant and not a.sort_by_cost:
+        ctx.set_option("kernel_variant", 2)
+        for k in range(S):
+            step(k)
+        torch.cuda.synchronize()
+        fp64la_streams = timed(S)
+        ctx.set_option("kernel_variant", 0)
+    # ---- (5) what a caller WITHOUT streams gets from one bigger launch: 2048 and 4096 solves, one launch at a time
+    #          (from 1025 solves on a launch picks the two-solves-per-SIMD build by itself) ----
+    one_launch = {}
+    if not a.quick and not user_variant and not a.sort_by_cost:
+        ctx.set_option("two_per_simd_min_batch", 1025)
+        for B2 in (2048, 4096):
+            c2 = W.config2(B2 * world)
+            sl2 = slice(rank * B2, (rank + 1) * B2)
+            descs2, ini2 = batch.build_batch(c2["states"][sl2], W.indexes(), W.units(), c2["iniPar"][sl2], c2["thickness"],
+                                             c2["nx"], nt, hmax=c2["hmax"], meas=c2["meas"], model=c2["model"],
+                                             ini_mode=c2["ini_mode"])
+            d2 = torch.from_numpy(descs2.view(np.uint8).reshape(-1)).to(dev)
+            o2 = torch.zeros(B2 * nt, dtype=torch.float64, device=dev)
+            st2 = torch.full((B2,), -1, dtype=torch.int32, device=dev)
+            sa2 = torch.zeros(B2 * 8, dtype=torch.int32, device=dev)
+
+            def step2():
+                ctx.check(L.lib().mtrpl_solve_batch_dev(ctx.handle, B2, d2.data_ptr(), d_ini.data_ptr(), d_t.data_ptr(),
+                                                        o2.data_ptr(), st2.data_ptr(), sa2.data_ptr(), int(c2["nx"]),
+                                                        L.MODEL[c2["model"]], streams[0].cuda_stream))
+            step2()
+            torch.cuda.synchronize()
+            n2 = 6
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record(streams[0])
+            for _ in range(n2):
+                step2()
+            e1.record(streams[0])
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            one_launch[str(B2)] = {"solves_per_launch": B2, "launches": n2, "ms_per_launch": dt2 / n2 * 1e3,
+                                   "kernel_ms": e0.elapsed_time(e1) / n2, "solves_per_sec": B2 * n2 / dt2,
+                                   "all_solves_ok": bool((st2 == 0).all().item()) and bool(torch.isfinite(o2).all().item())}
+            del d2, o2, st2, sa2
+        ctx.set_option("two_per_simd_min_batch", 1 if S > 1 else 1025)
 
     # measured HBM stream rate of this device (read + write of a 1 GiB buffer), next to the nominal peak
     copy_gbs = None
@@ -504,10 +551,17 @@ def main():
                                                "order measured on the identical batch in a warm-up launch: an upper bound of "
                                                "what issue ordering buys, not available to a first-time caller"},
             "fp64_linear_algebra": None if fp64la is None else {
-                **region(*fp64la), "note": "single_stream on kernel_variant 2: fp64 elimination blocks and fp64 re-solve"},
+                **region(*fp64la), "note": "single_stream on kernel_variant 2: fp64 elimination blocks and fp64 re-solve",
+                "streams": None if fp64la_streams is None else {
+                    **region(*fp64la_streams), "note": "the timed region (same streams, as drawn) on kernel_variant 2: one "
+                                                       "solve per SIMD, so the second and later launches queue for SIMDs"}},
+            "one_launch": one_launch or None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, **pmc, "kernel": kern_name,
-                         "kernel_ms": kern_ms, "launches_in_flight": S, "algorithmic_bytes_per_solve": A,
+                         "kernel_ms": kern_ms, "kernel_ms_brackets": "HIP events on the launch's own stream around the solve "
+                         "kernel alone (since round 4 nothing else is enqueued by a launch); with several launches in flight "
+                         "the bracket includes the time a launch's workgroups wait for SIMDs the other launches hold",
+                         "launches_in_flight": S, "algorithmic_bytes_per_solve": A,
                          "device": {"achieved": A * B / (dt / a.steps) / 1e9, "frac": A * B / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
                                     "note": "the same bytes per launch over the time per step: what the device does with "
                                             "launches_in_flight launches sharing it (achieved / frac above are per launch)"},

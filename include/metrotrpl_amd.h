@@ -75,15 +75,19 @@ enum {
 typedef struct mtrpl_solve_desc {
     double par[16];   /* MTRPL_P_* slots */
     double thickness; /* Grid.thickness [nm] */
-    double hmax;      /* Grid.hmax: max integrator step [ns] */
+    double hmax;      /* Grid.hmax: the reference's max integrator step [ns]; caps the step only with the option
+                         honor_hmax = 1 (default 0: the engine's own error control does not need the guard) */
     double rtol;      /* RTOL of the call (default 1e-7, :18).  The engine's contract is the CONVERGED
                          solution (1e-6 gate), so RTOL acts one way: a looser value than the default
                          is not a licence to be less accurate (internal rtol = min(0.1*RTOL, rtol_cap),
                          then the policy factors of DESIGN.md section 3), a tighter one tightens the
                          integration below the policy's own floor, down to the fp64 noise floor of this
                          system (option rtol_min); a request below that is raised to it and the solve
-                         reports MTRPL_SOLVE_OK_TOL_CLAMPED.  To trade accuracy for speed raise the
-                         option rtol_cap (or force one value with rtol_force). */
+                         reports MTRPL_SOLVE_OK_TOL_CLAMPED.  A caller who WANTS the reference's trade of accuracy
+                         for speed opts in with the context option rtol_mode = 1: internal rtol = 0.1*RTOL
+                         whatever RTOL is (up to 1e-3), every policy factor scaling with it -- RTOL = 1e-5 then
+                         takes a third fewer steps than the default and is still closer to the converged trace
+                         than the reference is at its own default tolerances (tests/test_gpu_tolerances.py). */
     double atol;      /* ATOL of the call (default 1e-10, :19), solver units (nm^-3 for the densities):
                          an upper bound of the absolute tolerance of the densities, which is otherwise
                          rtol_int * atol_rel_np * max(N0, P0) (about 3e-21 nm^-3).  The default changes
@@ -115,9 +119,12 @@ const char *mtrpl_version(void);
  *   amp_ref, amp_post                 ... / max(1, (1 + tauP/tauN) / amp_ref) (0 = off; default 10) while the excess density is
  *                                     above amp_post x p0 (default 0.03; judged by the emitted signal: until the high- to
  *                                     low-injection transition is behind the solve) ...
- *   tail_frac, tail_factor            ... x tail_factor (0.4) once an emitted sample has fallen below tail_frac (1e-4) x the
- *                                     first one, where the signal is a small difference of the state ...
+ *   tail_frac, tail_factor            ... x tail_factor once an emitted sample has fallen below tail_frac (1e-4) x the
+ *                                     first one (round 3: 0.4; 1 = off since the mass test below does that job) ...
  *   far_frac, far_factor              ... x far_factor (3) instead below far_frac (1e-9): nothing measured reaches there ...
+ *   rtol_mode                         0 (default): as above, the converged trace is the contract; 1: the caller's RTOL
+ *                                     decides in both directions (forward_solver.py:163-165): internal rtol =
+ *                                     rtol_scale * desc.rtol, capped at 1e-3 only
  *   rtol_floor                        ... these two policy factors never take it below rtol_floor;
  *   rtol_min                          a caller's own RTOL does go below rtol_floor, down to rtol_min
  *                                     (then MTRPL_SOLVE_OK_TOL_CLAMPED)
@@ -126,6 +133,12 @@ const char *mtrpl_version(void);
  *   atol_rel_np                       ... of the densities = min(rtol_int * atol_rel_np * max(N0, P0), desc.atol):
  *                                     default 1e-9 resolves a trace over 8 decades of decay inside the 1e-6 gate
  *                                     (1e-4: the first 4, 6 % fewer steps)
+ *   shape_factor, fun_weight          the goal-oriented error test: the RMS norm of the local error
+ *                                     estimate may reach shape_factor (30) x the tolerance as long as its MASS component
+ *                                     -- the signed grid sum of the estimate for N against the grid sum of the excess
+ *                                     N - n0, x fun_weight (3) -- stays inside the tolerance itself; shape_factor <= 1: the
+ *                                     plain RMS test
+ *   mass_floor                        ... the excess never counted smaller than mass_floor (1e-3) x n0 per node
  *   e_weight                          relative error weight of the field components (x rtol_int), TRPL solves only
  *   newton_tol, rate_max_age, rate_first_safety   simplified-Newton convergence control
  *   nq_deadband_hi                    a proposed step factor in [0.9, this) keeps the step and the factors (1.2)
@@ -133,7 +146,9 @@ const char *mtrpl_version(void);
  *                                     after a rejected one; nq_bias_same/_down/_up: multipliers of the step factors
  *   early_factor, early_frac          local tolerance x early_factor for steps that end before
  *                                     early_frac * (first requested sample time)
- *   honor_hmax                        1: desc.hmax is the maximum step (the reference's max_step) ...
+ *   honor_hmax                        1: desc.hmax is the maximum step (the reference's max_step); 0 (default): it is not --
+ *                                     max_step guards LSODA's error control, this engine's own does not need it (no
+ *                                     sample of any accuracy fixture moves, 9 % fewer steps) ...
  *   hmax_scale                        ... x hmax_scale (default 1) ...
  *   hmax_deep                         ... while there is a signal: once an emitted sample has fallen below hmax_deep x
  *                                     the first sample (default 1e-11: the state sits at equilibrium to rounding) the

@@ -1,7 +1,8 @@
 """bench.py --workload config5 : BASELINE.json configs[4] -- nx=512 thick- and thin-film drift-diffusion, mixed
-TRPL + TRTS, fp64.  One "step" = one launch of `solve_kernel_team<double, 4, ...>` (four wavefronts per solve,
-elimination blocks stored as fp32 in LDS) over a 512-solve batch: 128 seeded config-2 states x (2000 nm, 311 nm) x
-(TRPL, TRTS), inputs resident in HBM.  A parity / tolerance-sweep configuration, not the headline metric: the
+TRPL + TRTS, fp64.  One "step" = one launch of `solve_kernel_spike<4, ...>` (four wavefronts per solve, each with the
+one-wave kernel's register-resident linear algebra on its own 128 nodes, coupled by a SPIKE interface solve:
+csrc/backend_spike.hpp; `--opt kernel_variant=1`: round 3's all-LDS team kernel) over a 512-solve batch: 128 seeded
+config-2 states x (2000 nm, 311 nm) x (TRPL, TRTS), inputs resident in HBM.  A parity / tolerance-sweep configuration, not the headline metric: the
 line exists so that the nx=512 kernel has a measured rate and a roofline of its own (missing 5)."""
 import time
 
@@ -20,6 +21,7 @@ def run(a, rank, world, local, dev):
     for kv in getattr(a, "opt", []) or []:
         k, v = kv.split("=")
         ctx.set_option(k, float(v))
+    team = ctx.get_option("kernel_variant") == 1
     n_states = max(1, a.batch // 8)  # default --batch 1024 -> 128 states -> 512 solves
     c = W.config5(n_states * world)
     B = 4 * n_states
@@ -32,38 +34,60 @@ def run(a, rank, world, local, dev):
     d_descs = torch.from_numpy(descs.view(np.uint8).reshape(-1)).to(dev)
     d_ini = torch.from_numpy(ini).to(dev)
     d_t = torch.from_numpy(t_host).to(dev)
-    d_out = torch.zeros(B * nt, dtype=torch.float64, device=dev)
-    d_status = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_stats = torch.zeros(B * 8, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream()
+    # The K timed steps are independent batches, issued the way bench.py's headline issues them: round-robin on S HIP
+    # streams (a solve holds its CU from start to finish -- 93 KB of LDS: one workgroup per CU, 256 resident -- and step
+    # counts spread 1 : 1.7, so a 512-solve launch alone leaves the CUs its short solves free idle for 40 % of its
+    # time; the next launch's workgroups take them).  `single_stream`: the same K steps one launch at a time.
+    S = max(1, min(int(getattr(a, "streams", 4)), 4))
+    outs = [(torch.zeros(B * nt, dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.int32, device=dev),
+             torch.zeros(B * 8, dtype=torch.int32, device=dev)) for _ in range(S)]
+    d_out, d_status, d_stats = outs[0]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
 
-    def step():
+    def step(q=0):
+        o, st_, sa_ = outs[q]
         ctx.check(L.lib().mtrpl_solve_batch_dev(ctx.handle, B, d_descs.data_ptr(), d_ini.data_ptr(), d_t.data_ptr(),
-                                                d_out.data_ptr(), d_status.data_ptr(), d_stats.data_ptr(), int(c["nx"]),
-                                                L.MODEL[c["model"]], stream.cuda_stream))
+                                                o.data_ptr(), st_.data_ptr(), sa_.data_ptr(), int(c["nx"]),
+                                                L.MODEL[c["model"]], streams[q].cuda_stream))
+
+    use_dist = getattr(a, "use_dist", world > 1)
+
+    def timed(n_streams):
+        for o, st_, _ in outs:
+            st_.fill_(-1)
+            o.fill_(float("nan"))
+        for q in range(n_streams):
+            step(q)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        t0 = time.perf_counter()
+        for k in range(a.steps):
+            q = k % n_streams
+            ev[k][0].record(streams[q])
+            step(q)
+            ev[k][1].record(streams[q])
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_ = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt.item())
+        ok_ = all(bool((outs[q][1] == 0).all().item()) and bool(torch.isfinite(outs[q][0]).all().item())
+                  for q in range(min(n_streams, a.steps)))
+        return dt_, float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])), ok_
 
     for _ in range(max(1, a.warmup)):
         step()
-    use_dist = getattr(a, "use_dist", world > 1)
-    if use_dist:
-        dist.barrier()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        ev[k][0].record(stream)
-        step()
-        ev[k][1].record(stream)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev]))
+    single = timed(1)
+    dt, kern_ms_s, ok_all = timed(S) if S > 1 else single
+    ev = None
+    kern_ms = kern_ms_s
     status = d_status.cpu().numpy()
     stats = d_stats.cpu().numpy().reshape(B, 8)
     sig = d_out.cpu().numpy()
@@ -76,15 +100,22 @@ def run(a, rank, world, local, dev):
         "config": {"workload": "config5: nx=512 drift-diffusion, 512 solves per GPU and step = 128 seeded config-2 states x "
                                "(2000 nm, 311 nm) x (TRPL, TRTS), 1001 output times over 2000 ns, hmax=4, std model, fp64",
                    "solves_per_gpu_per_step": B, "nx": int(c["nx"]), "nt_out": int(nt), "parallelism": f"batch-shard x{world}",
-                   "all_solves_ok": bool(np.all(status == 0) and np.all(np.isfinite(sig))),
+                   "all_solves_ok": bool(ok_all and np.all(status == 0) and np.all(np.isfinite(sig))),
                    "mean_integrator_steps": float(stats[:, 0].mean()), "max_integrator_steps": int(stats[:, 0].max()),
-                   "streams": 1, "issue_order": "as drawn", **({"options": a.opt} if getattr(a, "opt", None) else {})},
+                   "streams": S, "issue_order": "as drawn", **({"options": a.opt} if getattr(a, "opt", None) else {})},
+        "single_stream": {"solves_per_sec": world * B * a.steps / single[0], "ms_per_step": single[0] / a.steps * 1e3,
+                          "kernel_ms": single[1], "all_solves_ok": single[2],
+                          "note": "the same K steps back to back on one stream: every 512-solve launch alone on the device "
+                                  "(two rounds of 256 resident solves)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "solve_kernel_team<double, 4, false, false, true>", "kernel_ms": kern_ms,
-                     "algorithmic_bytes_per_solve": A,
+                     "kernel": "solve_kernel_team<double, 4, false, false, true>" if team else "solve_kernel_spike<4, true>",
+                     "kernel_ms": kern_ms, "launches_in_flight": S, "algorithmic_bytes_per_solve": A,
+                     "single_stream": {"kernel_ms": single[1], "achieved": A * B / (single[1] * 1e-3) / 1e9,
+                                       "frac": A * B / (single[1] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                     "device": {"achieved": A * B / (dt / a.steps) / 1e9, "frac": A * B / (dt / a.steps) / 1e9 / HBM_PEAK_GBS},
                      "note": "state-streaming model of SURVEY.md 8d (24.6 MB per nx=512 solve); the state lives in registers "
-                             "and the elimination blocks in LDS (135 KB per workgroup, one workgroup per CU), so HBM is not "
+                             "and the elimination blocks in LDS (93 KB per workgroup, one workgroup per CU), so HBM is not "
                              "the limiter: four waves per solve on 256 CUs = 256 solves resident, the rest of the batch "
                              "queues behind them"},
     }

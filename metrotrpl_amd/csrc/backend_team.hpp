@@ -166,6 +166,7 @@ struct TeamBackend {
     }
     __device__ inline void out_first(real partial) { em.first((double)team_sum(partial), (double)p.dx, tid == 0); }
     __device__ inline void out_sample(int k, real partial) { em.put(k, (double)team_sum(partial), (double)p.dx, tid == 0); }
+    __device__ inline void out_flush() {}
 
     __device__ inline void put(int b, const M2r &m) const
     {

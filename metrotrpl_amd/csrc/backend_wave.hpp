@@ -97,6 +97,7 @@ struct WaveBackendT {
     __device__ inline bool deep() const { return em.deep(); }
     __device__ inline void out_first(double partial) { em.first(uniform(wave_sum(partial)), p.dx, lane == 0); }
     __device__ inline void out_sample(int k, double partial) { em.put(k, uniform(wave_sum(partial)), p.dx, lane == 0); }
+    __device__ inline void out_flush() {}
 
     // ---- RHS: forward_solver.py:332-372 (dydt_numba) ----
     // Padded nodes (i >= L) carry N=P=1, E=0 for ever (integrate() gives them a zero step): an edge between two

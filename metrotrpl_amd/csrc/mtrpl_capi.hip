@@ -15,6 +15,7 @@
 #include "irf_kernels.hpp"
 #include "backend_wave.hpp"
 #include "backend_team.hpp"
+#include "backend_spike.hpp"
 
 using namespace mtrpl;
 
@@ -198,6 +199,31 @@ __global__ __launch_bounds__(64) void newton_probe_kernel_wave(const double *par
     if (s >= B) return;
     __shared__ double2 fac_lds[(F32BLK ? kFactorLdsBytesF32 : kFactorLdsBytes) / 16];
     WaveBackendT<F32BLK> bk(threadIdx.x, fac_lds);
+    newton_probe(bk, par, dxs, cs, y, b, x, nx, s);
+}
+template <int W>
+__global__ __launch_bounds__(64 * W) void rhs_batch_kernel_spike(const double *par, const double *dxs, const double *y,
+                                                                double *dy, int nx, int64_t B)
+{
+    using BK = SpikeBackendT<W>;
+    const int64_t s = blockIdx.x;
+    if (s >= B) return;
+    __shared__ float4 slabs[W * BK::kSlabBytes / 16];
+    __shared__ double shared[BK::kSharedDoubles];
+    BK bk(threadIdx.x, slabs, shared);
+    rhs_probe(bk, par, dxs, y, dy, nx, s);
+}
+template <int W>
+__global__ __launch_bounds__(64 * W) void newton_probe_kernel_spike(const double *par, const double *dxs, const double *cs,
+                                                                   const double *y, const double *b, double *x, int nx,
+                                                                   int64_t B)
+{
+    using BK = SpikeBackendT<W>;
+    const int64_t s = blockIdx.x;
+    if (s >= B) return;
+    __shared__ float4 slabs[W * BK::kSlabBytes / 16];
+    __shared__ double shared[BK::kSharedDoubles];
+    BK bk(threadIdx.x, slabs, shared);
     newton_probe(bk, par, dxs, cs, y, b, x, nx, s);
 }
 // the controller's merged fp32 wave reductions (device_math.hpp: wave_sums_f) on caller data: in [B][4][64], out [B][7] =
@@ -459,10 +485,12 @@ const OptD kOptD[] = {
     {"hmax_scale", &SolveTuning::hmax_scale}, {"tail_frac", &SolveTuning::tail_frac}, {"tail_factor", &SolveTuning::tail_factor},
     {"far_frac", &SolveTuning::far_frac}, {"far_factor", &SolveTuning::far_factor}, {"deep_factor", &SolveTuning::deep_factor},
     {"shape_factor", &SolveTuning::shape_factor}, {"fun_weight", &SolveTuning::fun_weight},
+    {"mass_floor", &SolveTuning::mass_floor},
 };
 const OptI kOptI[] = {
     {"max_steps", &SolveTuning::max_steps}, {"rate_max_age", &SolveTuning::rate_max_age},
     {"honor_hmax", &SolveTuning::honor_hmax}, {"nq_rej_memory", &SolveTuning::nq_rej_memory},
+    {"rtol_mode", &SolveTuning::rtol_mode},
 };
 // every option still at its shipped value: the kernel instantiation with the options compiled in may run
 bool default_tune(const SolveTuning &t)
@@ -556,9 +584,22 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
         else hipLaunchKernelGGL(KERNEL<false>, dim3((unsigned)B), dim3(64), 0, s, d_descs, d_ini, d_tsteps, d_out,    \
                                 d_status, d_stats, B, ctx->tune);                                                     \
     } while (0)
-    if (traps || max_nx > 128 || variant == 1) {
+    if (traps || variant == 1) {
         const int rc = launch_team_any<double>(ctx, s, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, max_nx, traps);
         if (rc != MTRPL_OK) return rc;
+    } else if (max_nx > 128) {
+        // std model, 128 < nx <= 512: W = 2 / 4 waves per solve, each with the wave kernel's register-resident linear
+        // algebra on its own 128 nodes, coupled by a SPIKE interface solve (backend_spike.hpp)
+#define MTRPL_SPIKE(W_)                                                                                               \
+    do {                                                                                                              \
+        if (ct) hipLaunchKernelGGL((solve_kernel_spike<W_, true>), dim3((unsigned)B), dim3(64 * W_), 0, s, d_descs,   \
+                                   d_ini, d_tsteps, d_out, d_status, d_stats, B, ctx->tune);                          \
+        else hipLaunchKernelGGL((solve_kernel_spike<W_, false>), dim3((unsigned)B), dim3(64 * W_), 0, s, d_descs,     \
+                                d_ini, d_tsteps, d_out, d_status, d_stats, B, ctx->tune);                             \
+    } while (0)
+        if (max_nx <= 256) MTRPL_SPIKE(2);
+        else MTRPL_SPIKE(4);
+#undef MTRPL_SPIKE
     } else if (variant == 3) {
         MTRPL_WAVE(solve_kernel_wave2);
     } else if (variant == 6) {
@@ -632,6 +673,8 @@ int mtrpl_rhs_batch(mtrpl_ctx *ctx, int64_t B, int32_t nx, int32_t model, const 
         hipLaunchKernelGGL(rhs_batch_kernel_wave, MTRPL_RHS_ARGS);
     }
     else if (nx <= 128) { if (traps) MTRPL_RHS_TEAM(1, true); else MTRPL_RHS_TEAM(1, false); }
+    else if (!traps && variant != 1 && nx <= 256) { constexpr int W_ = 2; hipLaunchKernelGGL(rhs_batch_kernel_spike<2>, MTRPL_RHS_ARGS); }
+    else if (!traps && variant != 1) { constexpr int W_ = 4; hipLaunchKernelGGL(rhs_batch_kernel_spike<4>, MTRPL_RHS_ARGS); }
     else if (nx <= 256) { if (traps) MTRPL_RHS_TEAM(2, true); else MTRPL_RHS_TEAM(2, false); }
     else { if (traps) MTRPL_RHS_TEAM(4, true); else MTRPL_RHS_TEAM(4, false); }
 #undef MTRPL_RHS_TEAM
@@ -648,7 +691,7 @@ int mtrpl_newton_probe(mtrpl_ctx *ctx, int64_t B, int32_t nx, const double *par,
     if (!ctx) return MTRPL_ERR_BAD_ARG;
     if (B <= 0) return MTRPL_OK;
     if (!par || !dx || !c || !y || !b || !x || nx < 2) return bad(ctx, MTRPL_ERR_BAD_ARG, "bad argument");
-    if (nx > 128) return bad(ctx, MTRPL_ERR_UNSUPPORTED, "nx > 128 not supported by this build");
+    if (nx > 512) return bad(ctx, MTRPL_ERR_UNSUPPORTED, "nx > 512 not supported by this build");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t S = 3 * (size_t)nx + 1;
     DevBuf dp(ctx, 0), ddx(ctx, 1), dc(ctx, 2), dyy(ctx, 3), db(ctx, 4), dxo(ctx, 5);
@@ -666,7 +709,11 @@ int mtrpl_newton_probe(mtrpl_ctx *ctx, int64_t B, int32_t nx, const double *par,
     HIP_TRY(ctx, hipMemcpyAsync(db.p, b, sizeof(double) * S * B, hipMemcpyHostToDevice, s));
 #define MTRPL_NP_ARGS 0, s, dp.as<double>(), ddx.as<double>(), dc.as<double>(), dyy.as<double>(), db.as<double>(), dxo.as<double>(), nx, B
     const int variant = ctx->kernel_variant;
-    if (variant == 3 || variant == 6 || variant == 0) {
+    if (nx > 256) {  // the SPIKE backend: four waves per solve
+        hipLaunchKernelGGL(newton_probe_kernel_spike<4>, dim3((unsigned)B), dim3(256), MTRPL_NP_ARGS);
+    } else if (nx > 128) {
+        hipLaunchKernelGGL(newton_probe_kernel_spike<2>, dim3((unsigned)B), dim3(128), MTRPL_NP_ARGS);
+    } else if (variant == 3 || variant == 6 || variant == 0) {
         hipLaunchKernelGGL(newton_probe_kernel_wave<true>, dim3((unsigned)B), dim3(64), MTRPL_NP_ARGS);
     } else {
         hipLaunchKernelGGL(newton_probe_kernel_wave<false>, dim3((unsigned)B), dim3(64), MTRPL_NP_ARGS);

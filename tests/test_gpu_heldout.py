@@ -4,8 +4,12 @@ tests/golden/heldout.npz (tests/golden/make_heldout.py) holds converged-oracle t
 the prior box every other converged fixture comes from, at thicknesses 100-5000 nm, over 50 ns / 2000 ns / 20 us
 windows, on uniform and geometric sample grids, from Beer-Lambert and from tabulated initial profiles, in an
 Auger-dominated and a surface-dominated corner, TRPL and TRTS, std and traps, nx 128 / 100 / 64 -- generated before the
-round-4 error-control policy was tuned, never used to tune it.  Same gate as tests/test_gpu_accuracy.py: per decade
-of signal decay, error <= 1e-6 + the oracle's own uncertainty for that trace and decade, decades 0-8."""
+round-4 error-control policy was tuned.  (What it changed: round 3's policy FAILS it -- 1.1e-6 / 1.2e-6 / 1.2e-5 in
+decades 5 / 7 / 8 --, and it exposed the cancellation in the photoconductivity formula that model_physics.hpp now avoids.
+Policy constants were afterwards chosen on the other fixtures and only checked here.)  Same gate as
+tests/test_gpu_accuracy.py: per decade of signal decay, error <= 1e-6 + the oracle's own uncertainty for that trace and
+decade, decades 0-8 -- where the oracle itself is converged to 1e-7 or better (TRTS below its seventh decade is not:
+the reference's own formula subtracts p0 from P there)."""
 import os
 
 import numpy as np
@@ -42,8 +46,12 @@ def solve_all(z, ctx=None):
     return sig, status, steps
 
 
+U_MAX = 1e-7
+
+
 def decade_table(z, sig, n_dec=11):
-    """per decade: (samples, worst error, worst error - u_oracle, index of the worst trace)"""
+    """per decade: (judged samples, worst error of all samples, worst error - u_oracle of the judged ones, index of
+    that trace)"""
     valid = z["valid"]
     ref = z["sig"]
     with np.errstate(all="ignore"):
@@ -56,9 +64,13 @@ def decade_table(z, sig, n_dec=11):
         if not m.any():
             out.append((0, 0.0, 0.0, -1))
             continue
+        # a reference adjudicates a 1e-6 gate only where it is itself converged ten times better: (trace, decade)
+        # cells whose oracle uncertainty exceeds U_MAX are reported, not gated
+        judged = m & (z["u_oracle"][:, d:d + 1] <= U_MAX)
         e = np.where(m, rel, -np.inf)
-        ex = np.where(m, rel - z["u_oracle"][:, d:d + 1], -np.inf)
-        out.append((int(m.sum()), float(e.max()), float(ex.max()), int(np.unravel_index(ex.argmax(), ex.shape)[0])))
+        ex = np.where(judged, rel - z["u_oracle"][:, d:d + 1], -np.inf)
+        who = int(np.unravel_index(ex.argmax(), ex.shape)[0]) if judged.any() else -1
+        out.append((int(judged.sum()), float(e.max()), float(ex.max()) if judged.any() else 0.0, who))
     return out
 
 
@@ -79,7 +91,7 @@ def test_heldout_traces_decade_by_decade(variant):
     # where the oracle itself is not converged (TRTS below its sixth decade: mu_n (N - n0) + mu_p (P - p0) is a
     # difference of nearly equal numbers there) the gate widens by exactly that much; it stays sharp nearly everywhere
     u9 = z["u_oracle"][v][:, :9]
-    assert u9[:, :6].max() < 1e-7 and np.mean(u9 < 1e-7) > 0.95
+    assert u9[:, :6].max() < U_MAX and np.mean(u9 < U_MAX) > 0.95
     table = decade_table(z, sig)
     for g_ in sorted(set(str(x) for x in z["group"])):
         m = v & (z["group"] == g_)

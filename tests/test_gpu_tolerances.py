@@ -69,14 +69,19 @@ def _atol_case():
     ref = z["sig"][sel]
     base, st0, stats0 = _solve(z, sel)
     same, st1, stats1 = _solve(z, sel, atol=1e-3)      # looser than the rule (about 3e-22 nm^-3): nothing changes
-    deep, st2, stats2 = _solve(z, sel, atol=1e-26)     # a smaller ATOL resolves a still deeper tail
+    deep, st2, stats2 = _solve(z, sel, atol=1e-26)     # a smaller ATOL: a tighter absolute term in the RMS weights
     assert np.all(st0 == 0) and np.all(st2 == 0)
     np.testing.assert_array_equal(same, base)
     e_base, e_deep = _err(base, ref, 9, 12), _err(deep, ref, 9, 12)
     print(f"decades 9-11: default {e_base:.2e} ({stats0[:, 0].mean():.0f} steps), ATOL=1e-26 {e_deep:.2e} "
           f"({stats2[:, 0].mean():.0f} steps)")
-    assert stats2[:, 0].mean() > 1.005 * stats0[:, 0].mean(), (stats2[:, 0].mean(), stats0[:, 0].mean())
-    assert e_deep < 0.9 * e_base  # (two-fold with round 2's ten times larger default floor)
+    # Since round 4 the error test that binds in a deep tail is the MASS test -- the signed grid sum of the error
+    # estimate against the grid sum of N, purely relative -- and the absolute term only sits in the weights of the
+    # shape (RMS) test, which is allowed 30x the tolerance: a smaller ATOL is honoured (the weights change, a few
+    # solves take a few more steps) but no longer buys two-fold accuracy down there (round 3: it did, at +0.5 % steps).
+    assert not np.array_equal(deep, base)
+    assert stats2[:, 0].mean() >= 0.999 * stats0[:, 0].mean()
+    assert e_deep <= 1.1 * e_base
     # the field keeps its own absolute floor: a tiny ATOL does not send the integrator crawling
     assert stats2[:, 0].max() < 3 * stats0[:, 0].max()
 
@@ -127,14 +132,58 @@ def test_atol_zero_is_integrated_like_the_reference_does():
         assert np.all(np.isfinite(sig)) and np.all(stats[:, 5] == 0)  # no Newton failure
         assert _err(sig, ref, 0, 9) <= 1e-6
         assert stats[:, 0].max() < 3 * stats0[:, 0].max()
-    # the traps model starts from a trapped density of exactly zero
-    team = np.load(os.path.join(G, "team_cases.npz"))
-    idx = {n: i for i, n in enumerate(str(team["traps_names"]).split(","))}
-    t0, s0, _ = batch.solve_batch(team["traps_states"][:2], idx, team["traps_units"], team["traps_ini"][:2],
-                                  team["traps_thickness"][:2], 128, team["traps_t"], model="traps", return_stats=True)
-    t1, s1, x1 = batch.solve_batch(team["traps_states"][:2], idx, team["traps_units"], team["traps_ini"][:2],
-                                   team["traps_thickness"][:2], 128, team["traps_t"], model="traps", ATOL=0.0,
-                                   return_stats=True)
-    assert np.all(s0 == 0) and np.all(s1 == 0) and np.all(x1[:, 5] == 0)
-    m = np.abs(t0) >= 1e-4 * np.abs(t0[:, :1])
-    assert np.max(np.abs(t1 - t0)[m] / np.abs(t0)[m]) < 1e-6
+    # (The traps model starts from a trapped density of exactly ZERO: with ATOL = 0 its error weight is 1/0 in the
+    # reference too -- ODEPACK stops with "ewt(i) <= 0" and the reference zero-fills -- so there is nothing to match.)
+
+def test_rtol_mode_caller_trades_accuracy_for_speed_like_the_reference():
+    """forward_solver.py:163-165 hands the caller's RTOL to LSODA: a looser RTOL is a faster solve.  By default the
+    engine's contract is the converged trace and a loose RTOL changes nothing; with the context option rtol_mode = 1
+    the caller's RTOL decides (internal rtol = 0.1 x RTOL, every policy factor scaling with it).  On every `__default`
+    golden of configs 1-3 that has a converged trace: RTOL = 1e-5 -- a hundred times LOOSER than the reference's own
+    default -- takes at least a quarter fewer steps than the default, and its error against the converged trace is
+    still no worse than that of the reference's default-tolerance output."""
+    from metrotrpl_amd import _lib as L, batch
+    from tests.test_gpu_solver import _case, _relerr
+    gold = np.load(os.path.join(G, "solve.npz"))
+    conv = np.load(os.path.join(G, "solve_converged.npz"))
+    ctx = L.default_context()
+
+    def run(c, rtol):
+        idx = {n: i for i, n in enumerate(c["names"])}
+        sig, st, stats = batch.solve_batch(c["state"][None, :], idx, c["units"], [c["iniPar"]], c["thickness"], c["nx"],
+                                           c["tSteps"], hmax=c["hmax"], meas=c["meas"], model=c["model"],
+                                           ini_mode=c["ini_mode"], RTOL=rtol, ATOL=c["atol"], return_stats=True)
+        assert st[0] == 0
+        return sig[0], int(stats[0, 0])
+
+    rows = []
+    for key in [str(k) for k in gold["order"]]:
+        ck = key.replace("__default", "__conv")
+        if not key.endswith("__default") or not key.startswith(("cfg1", "cfg2", "cfg3")) or ck not in conv.files:
+            continue
+        c = _case(gold, key)
+        if c["model"] != "std" or c["nx"] > 128 or c["min_y"] is not None:
+            continue
+        base, n_base = run(c, c["rtol"])
+        assert ctx.get_option("rtol_mode") == 0
+        same, n_same = run(c, 1e-5)  # default mode: a loose RTOL is not a licence
+        np.testing.assert_array_equal(same, base)
+        ctx.set_option("rtol_mode", 1)
+        try:
+            loose, n_loose = run(c, 1e-5)
+            as_ref, n_ref = run(c, c["rtol"])  # the reference's own RTOL in caller mode: internal 1e-8
+        finally:
+            ctx.set_option("rtol_mode", 0)
+        e_loose, e_asref = _relerr(loose, conv[ck])[0], _relerr(as_ref, conv[ck])[0]
+        ref_gap = _relerr(c["sig"], conv[ck])[0]
+        rows.append((key, n_base, n_loose, n_ref, e_loose, e_asref, ref_gap))
+        print(f"{key}: steps default {n_base}, caller 1e-5 {n_loose}, caller 1e-7 {n_ref} | error vs converged: caller 1e-5 "
+              f"{e_loose:.2e}, caller 1e-7 {e_asref:.2e}, reference at its default {ref_gap:.2e}")
+    assert len(rows) >= 12
+    n_base, n_loose = np.array([r[1] for r in rows]), np.array([r[2] for r in rows])
+    assert n_loose.sum() <= 0.75 * n_base.sum(), (n_loose.sum(), n_base.sum())
+    assert np.all(n_loose < n_base)
+    # no worse than the reference at ITS default tolerances: case by case at RTOL = 1e-7, in the worst case at 1e-5
+    for key, _, _, _, e_loose, e_asref, ref_gap in rows:
+        assert e_asref <= max(ref_gap, 1e-6), (key, e_asref, ref_gap)
+    assert max(r[4] for r in rows) <= max(r[6] for r in rows)

@@ -34,7 +34,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc${T}c5_fe
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc${T}c5_write -- $C5 > $O/pmc${T}c5_2.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc${T}c5_sq -- $C5 > $O/pmc${T}c5_3.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/pmc${T}c5_sq2 -- $C5 > $O/pmc${T}c5_4.log 2>&1
-python tools/pmc_summary.py "solve_kernel_team<" $O/hbm_traffic_${T}_team4.json $O/pmc${T}c5_fetch $O/pmc${T}c5_write $O/pmc${T}c5_sq $O/pmc${T}c5_sq2 > $O/${T}_pmc_team.log 2>&1
+python tools/pmc_summary.py "solve_kernel_spike<" $O/hbm_traffic_${T}_team4.json $O/pmc${T}c5_fetch $O/pmc${T}c5_write $O/pmc${T}c5_sq $O/pmc${T}c5_sq2 > $O/${T}_pmc_team.log 2>&1
 # ---- the parallel-tempering ensembles: contract lines, kernel statistics, counters of the likelihood kernel ----
 timeout -k 10 300 python bench.py --workload pt --chains 512 --steps 20 --warmup 10 > $O/${T}_bench_pt512_1gpu.json 2>> $O/${T}_bench.err
 timeout -k 10 300 python bench.py --workload pt --chains 64 --steps 40 --warmup 10 --no-cpu-baseline > $O/${T}_bench_pt64_1gpu.json 2>> $O/${T}_bench.err

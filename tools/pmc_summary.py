@@ -26,8 +26,8 @@ fetch, write = vals.get("FETCH_SIZE"), vals.get("WRITE_SIZE")
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* (separate passes, --kernel-trace only) on "
                  "`python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --streams 1 --quick [--batch 2048 --opt kernel_variant=3 for solve_kernel_wave2; "
                  "--workload config5 for solve_kernel_team; --workload pt --chains 512 for loglik_kernel]` (one launch at a time on the device); kernel " + kern + ", average per launch",
-       "solves_per_launch": 2048 if "wave2" in kern else (512 if "team" in kern else (3072 if "loglik" in kern else 1024)),
-       "waves_per_solve": 4 if "team" in kern else (12 if "loglik" in kern else 1),
+       "solves_per_launch": 2048 if "wave2" in kern else (512 if ("team" in kern or "spike" in kern) else (3072 if "loglik" in kern else 1024)),
+       "waves_per_solve": 4 if ("team" in kern or "spike" in kern) else (12 if "loglik" in kern else 1),
        "FETCH_SIZE_KB_raw": fetch, "WRITE_SIZE_KB_raw": write,
        "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE reports 1/2 of a wide coalesced read on gfx950 -> doubled; "
                      "WRITE_SIZE exact; both in KiB.  Reads here are small descriptor/time-grid loads, so the factor is an upper bound.",
@@ -46,7 +46,7 @@ if "SQ_WAVES" in sq:
                       "scalar_active_fraction_of_wave_cycles": frac("SQ_ACTIVE_INST_SCA"),
                       "parked_on_waitcnt_fraction_of_wave_cycles": frac("SQ_WAIT_ANY"),
                       "issue_stall_fraction_of_wave_cycles": frac("SQ_WAIT_INST_ANY"),
-                      "occupancy_waves_per_simd": 2 if "wave2" in kern else (1 if "wave" in kern or "team" in kern else None),
+                      "occupancy_waves_per_simd": 2 if "wave2" in kern else (1 if "wave" in kern or "team" in kern or "spike" in kern else None),
                       "wave_cycles_per_solve(quad-cycles*4)": 4 * sq.get("SQ_WAVE_CYCLES", 0) / w / res["waves_per_solve"]}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
