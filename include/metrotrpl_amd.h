@@ -121,7 +121,7 @@ const char *mtrpl_version(void);
  *                                     low-injection transition is behind the solve) ...
  *   tail_frac, tail_factor            ... x tail_factor once an emitted sample has fallen below tail_frac (1e-4) x the
  *                                     first one (round 3: 0.4; 1 = off since the mass test below does that job) ...
- *   far_frac, far_factor              ... x far_factor (3) instead below far_frac (1e-9): nothing measured reaches there ...
+ *   far_frac, far_factor              ... x far_factor (30; round 3: 3) instead below far_frac (1e-9): nothing measured reaches there ...
  *   rtol_mode                         0 (default): as above, the converged trace is the contract; 1: the caller's RTOL
  *                                     decides in both directions (forward_solver.py:163-165): internal rtol =
  *                                     rtol_scale * desc.rtol, capped at 1e-3 only

@@ -115,7 +115,7 @@ struct DefaultTune {
     static constexpr int rate_max_age = 8;
     static constexpr double rate_first_safety = 4.0, e_weight = 3.0;
     static constexpr int honor_hmax = 0;
-    static constexpr double hmax_deep = 1e-11, deep_factor = 1000.0, hmax_scale = 1.0, tail_frac = 1e-4, tail_factor = 1.0, far_frac = 1e-9, far_factor = 3.0, trts_rtol_factor = 0.5, amp_ref = 10.0, amp_post = 0.03, nq_deadband_hi = 1.2;
+    static constexpr double hmax_deep = 1e-11, deep_factor = 1000.0, hmax_scale = 1.0, tail_frac = 1e-4, tail_factor = 1.0, far_frac = 1e-9, far_factor = 30.0, trts_rtol_factor = 0.5, amp_ref = 10.0, amp_post = 0.03, nq_deadband_hi = 1.2;
     static constexpr int nq_rej_memory = 80;
     static constexpr double nq_rej_growth = 1.2, nq_bias_same = 1.0, nq_bias_down = 1.0, nq_bias_up = 1.0;
     static constexpr double early_factor = 10.0, early_frac = 0.5;

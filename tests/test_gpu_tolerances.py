@@ -58,9 +58,9 @@ def test_atol_bounds_the_absolute_term():
     try:
         _atol_case()
     finally:
-        ctx.set_option("far_factor", 3.0)
+        ctx.set_option("far_factor", 30.0)
         ctx.set_option("deep_factor", 1000.0)
-    assert ctx.get_option("far_factor") == 3.0 and ctx.get_option("deep_factor") == 1000.0
+    assert ctx.get_option("far_factor") == 30.0 and ctx.get_option("deep_factor") == 1000.0
 
 
 def _atol_case():
@@ -77,10 +77,10 @@ def _atol_case():
           f"({stats2[:, 0].mean():.0f} steps)")
     # Since round 4 the error test that binds in a deep tail is the MASS test -- the signed grid sum of the error
     # estimate against the grid sum of N, purely relative -- and the absolute term only sits in the weights of the
-    # shape (RMS) test, which is allowed 30x the tolerance: a smaller ATOL is honoured (the weights change, a few
-    # solves take a few more steps) but no longer buys two-fold accuracy down there (round 3: it did, at +0.5 % steps).
+    # shape (RMS) test, which is allowed 30x the tolerance: a smaller ATOL is honoured (the weights change, some solves
+    # take a few steps more or fewer) but no longer buys two-fold accuracy down there (round 3: it did, at +0.5 % steps).
     assert not np.array_equal(deep, base)
-    assert stats2[:, 0].mean() >= 0.999 * stats0[:, 0].mean()
+    assert abs(stats2[:, 0].mean() / stats0[:, 0].mean() - 1.0) < 0.05
     assert e_deep <= 1.1 * e_base
     # the field keeps its own absolute floor: a tiny ATOL does not send the integrator crawling
     assert stats2[:, 0].max() < 3 * stats0[:, 0].max()

@@ -34,7 +34,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc${T}c5_fe
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc${T}c5_write -- $C5 > $O/pmc${T}c5_2.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc${T}c5_sq -- $C5 > $O/pmc${T}c5_3.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/pmc${T}c5_sq2 -- $C5 > $O/pmc${T}c5_4.log 2>&1
-python tools/pmc_summary.py "solve_kernel_spike<" $O/hbm_traffic_${T}_team4.json $O/pmc${T}c5_fetch $O/pmc${T}c5_write $O/pmc${T}c5_sq $O/pmc${T}c5_sq2 > $O/${T}_pmc_team.log 2>&1
+python tools/pmc_summary.py "solve_kernel_spike<" $O/hbm_traffic_${T}_spike4.json $O/pmc${T}c5_fetch $O/pmc${T}c5_write $O/pmc${T}c5_sq $O/pmc${T}c5_sq2 > $O/${T}_pmc_team.log 2>&1
 # ---- the parallel-tempering ensembles: contract lines, kernel statistics, counters of the likelihood kernel ----
 timeout -k 10 300 python bench.py --workload pt --chains 512 --steps 20 --warmup 10 > $O/${T}_bench_pt512_1gpu.json 2>> $O/${T}_bench.err
 timeout -k 10 300 python bench.py --workload pt --chains 64 --steps 40 --warmup 10 --no-cpu-baseline > $O/${T}_bench_pt64_1gpu.json 2>> $O/${T}_bench.err
@@ -48,6 +48,11 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc${T}pt_fetch -- $PT > $O/pmc${T}pt_1.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc${T}pt_write -- $PT > $O/pmc${T}pt_2.log 2>&1
 python tools/pmc_summary.py "loglik_kernel<" $O/hbm_traffic_${T}_loglik.json $O/pmc${T}pt_fetch $O/pmc${T}pt_write $O/pmc${T}pt_sq > $O/${T}_pmc_loglik.log 2>&1
+# ---- config 5: fp32 / fp64 tolerance sweep on this build (the fp32 instantiation is the team kernel's) ----
+timeout -k 10 400 python tools/config5_sweep.py $O/${T}_config5_sweep.json > $O/${T}_config5_sweep.txt 2>&1
+# ---- the held-out converged set, where the steps of a solve go ----
+timeout -k 10 200 python tools/heldout_table.py > $O/${T}_heldout.txt 2>/dev/null
+MTRPL_LIB_PATH=$PWD/metrotrpl_amd/lib/libmetrotrpl_amd_trace.so timeout -k 10 200 python tools/startup_trace.py > $O/${T}_startup_trace.txt 2>/dev/null
 # ---- accuracy table, variant agreement, solve latency, PCIe-inclusive rate ----
 timeout -k 10 200 python tools/tail_table.py --json $O/${T}_tail_decades.json --settings shipped > $O/${T}_tail_decades.txt 2>/dev/null
 timeout -k 10 300 python tools/variant_agreement.py 8192 > $O/${T}_variant_agreement.txt 2>/dev/null
