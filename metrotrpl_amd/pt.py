@@ -140,6 +140,17 @@ def replica_exchange(table, rng):
     return owner, attempts, accepts
 
 
+LOCAL_ONLY = object()  # `group` of a ONE-rank ensemble that must not touch the process group it happens to live in (bench.py's
+#                        one-GPU legs inside an N-rank job): no collective is issued, whatever torch.distributed has set up
+
+
+def _single(world, group):
+    """One rank and nothing to gather through: no process group initialised (or the caller said LOCAL_ONLY).  A one-rank
+    group that WAS set up (MTRPL_FORCE_DIST=1, tests/gpu_ensemble_child.py --dist 1) does go through the collective."""
+    import torch.distributed as dist
+    return world == 1 and (group is LOCAL_ONLY or not (dist.is_available() and dist.is_initialized()))
+
+
 class TableGather:
     """One evaluator call on this rank's block of every state array in `states_list` (each [n_chains,
     n_params]) at all ladder temperatures, and ONE all-gather of the results (RCCL on GPUs, gloo in the CPU
@@ -158,7 +169,7 @@ class TableGather:
         with (torch.cuda.stream(stream) if stream is not None else _Nothing()):
             local = evaluator(block, temperatures)
             self.nT = local.shape[1]
-            self.single = world == 1 and not (dist.is_available() and dist.is_initialized())
+            self.single = _single(world, group)
             if self.single:
                 dev_result = local
             else:
@@ -320,8 +331,7 @@ class PTEnsemble:
 
     def _collective(self):
         """Does a gather go through torch.distributed (more than one rank, or a one-rank group that was set up)?"""
-        import torch.distributed as dist
-        return self.world > 1 or (dist.is_available() and dist.is_initialized())
+        return not _single(self.world, self.group)
 
     def gather_table(self, states):
         """Evaluate the local block at all ladder temperatures, all-gather -> [n, nT] numpy."""
@@ -352,7 +362,7 @@ class PTEnsemble:
         c, nT, npar = self.hi - self.lo, self.T.shape[0], self.states.shape[1]
         dev = self.cur_tab.device
         host = np.concatenate([self.states[self.lo:self.hi], self.acc_count[self.lo:self.hi, None].astype(np.float64)], axis=1)
-        single = self.world == 1 and not (dist.is_available() and dist.is_initialized())
+        single = _single(self.world, self.group)
         if single:
             self.table = self.cur_tab.detach().cpu().numpy().copy()
             self._sync_logll()

@@ -112,8 +112,11 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
     eng, ens0, T, proposer = S["eng"], S["ens0"], S["T"], S["proposer"]
     # history-free draws (pt.PTEnsemble "counter" mode): the chain walked does not depend on N, on prefetching
     # or on the chain groups
+    # a ONE-rank ensemble that is not asked to rehearse the collectives (use_dist) never touches the process group it
+    # may happen to live in: bench.py runs such legs on rank 0 of an N-rank job while the other ranks wait
+    local_only = world == 1 and not getattr(a, "use_dist", False)
     ens = pt.PTEnsemble(ens0["chain_states"], T, S["evaluators"] if groups > 1 else S["evaluator"], rank=rank,
-                        world=world, rng_mode="counter", streams=S["streams"])
+                        world=world, rng_mode="counter", streams=S["streams"], group=pt.LOCAL_ONLY if local_only else None)
     ens.initialise()
     temper_freq = 10
     ens.advance(proposer, a.warmup, temper_freq, prefetch)
@@ -139,7 +142,7 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
     stats = eng.d_stats.cpu().numpy().reshape(-1, 8)
     # the slowest solve of a rank's last launch is what that rank's iteration waits for: one figure per rank
     steps_rank = [int(stats[:, 0].max())]
-    if getattr(a, "use_dist", world > 1):
+    if getattr(a, "use_dist", world > 1) and world > 1:
         mine = torch.tensor(steps_rank, dtype=torch.int64, device=dev)
         every = torch.zeros(world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(every, mine)

@@ -307,3 +307,45 @@ def test_reference_order_walk_sharded_equals_one_rank(mode):
     for r in res:
         for got, want in zip(r[1:], ref):
             np.testing.assert_array_equal(got, want)
+
+
+def _local_only_worker(rank, world, port, q):
+    """bench.py at N > 1: the ranks run a sharded ensemble together, THEN rank 0 runs one alone while the others wait
+    at a barrier.  The lone ensemble (group=pt.LOCAL_ONLY) must issue no collective on the job's process group -- it
+    would pair up with the others' barrier."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ens0 = W.pt_ensemble(8)
+    e = pt.PTEnsemble(ens0["chain_states"], ens0["temperatures"], _toy_evaluator, rank=rank, world=world, rng_mode="counter")
+    e.initialise()
+    e.advance(_proposer(), 8, 4, prefetch=True)
+    out = None
+    if rank == 0:
+        solo = pt.PTEnsemble(ens0["chain_states"], ens0["temperatures"], _toy_evaluator, rank=0, world=1, rng_mode="counter",
+                             group=pt.LOCAL_ONLY)
+        solo.initialise()
+        solo.advance(_proposer(), 8, 4, prefetch=True)
+        out = (solo.states.copy(), solo.logll.copy(), solo.n_collectives, e.states.copy(), e.n_collectives)
+    dist.barrier()
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_a_lone_ensemble_inside_a_two_rank_job_issues_no_collective():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_local_only_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=90) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    solo_states, solo_logll, solo_coll, shard_states, shard_coll = res[0]
+    assert solo_coll == 0 and shard_coll == 1 + 2  # initialise + two replica exchanges through gloo
+    ref, _, _ = _run_counter(8, 8, True)
+    np.testing.assert_array_equal(solo_states, ref.states)
+    np.testing.assert_array_equal(solo_logll, ref.logll)
+    np.testing.assert_array_equal(shard_states, ref.states)  # and the sharded walk is the same chain
