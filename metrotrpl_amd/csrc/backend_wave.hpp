@@ -35,6 +35,7 @@ struct WaveBackendT {
     using real = double;
     static constexpr int R = 2, V = 6;
     static constexpr bool TRAPS = false;
+    static constexpr bool kParksSamples = false;  // out_sample() parks, out_flush() emits
 
     Par p;
     int L, lane;
