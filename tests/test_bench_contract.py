@@ -118,3 +118,56 @@ def test_gpus_2_without_a_launcher_starts_nothing_on_a_gpu_less_box():
     assert r.returncode == 3, (r.returncode, r.stderr[-300:])
     assert r.stdout == ""
     assert "--gpus 2" in r.stderr and "GPU(s) visible" in r.stderr
+
+
+def test_round4_bench_line_tells_the_whole_story():
+    """The newest committed round-4 line (tools/final_profiles.sh on the MI355X box): measured as drawn with no ordering
+    kernel in front of a launch, the kernel time brackets the solve kernel alone and says so, and the figures VERDICT r3
+    asked for ride along: one launch at a time at 1024 / 2048 / 4096 solves, the all-fp64 kernel on one and on four
+    streams, both parallel-tempering ensembles with the slowest solve per rank."""
+    import glob
+    import json
+    path = sorted(glob.glob(os.path.join(REPO, "profiles", "r04_?_bench_config2.json")))[-1]
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    assert d["metric"] == "trpl_forward_solves_per_sec" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and d["n_gpus"] == 1 and d["data"] == "synthetic"
+    cfg = d["config"]
+    assert cfg["as_drawn"] is True and cfg["all_solves_ok"] is True and "model" not in cfg and "as drawn" in cfg["issue_order"]
+    assert cfg["solves_per_gpu_per_step"] == 1024 and cfg["nx"] == 128 and cfg["nt_out"] == 1001
+    assert cfg["mean_integrator_steps"] <= 900 and cfg["max_integrator_steps"] <= 1400  # VERDICT r3, next 2
+    assert "as_given" not in d  # the headline IS as given
+    for k in ("single_stream", "sorted_by_measured_cost", "fp64_linear_algebra"):
+        leg = d[k]
+        assert leg["all_solves_ok"] is True and leg["solves_per_sec"] > 1e5, k
+        assert abs(leg["solves_per_sec"] - 1024 / (leg["ms_per_step"] * 1e-3)) < 1e-6 * leg["solves_per_sec"], k
+    assert abs(d["value"] - 1024 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["single_stream"]["solves_per_sec"] < d["value"] < d["sorted_by_measured_cost"]["solves_per_sec"]
+    f64 = d["fp64_linear_algebra"]
+    assert f64["streams"]["all_solves_ok"] is True and f64["solves_per_sec"] < d["single_stream"]["solves_per_sec"]
+    assert f64["streams"]["solves_per_sec"] < d["value"]
+    for b2 in ("2048", "4096"):
+        o = d["one_launch"][b2]
+        assert o["all_solves_ok"] is True and o["solves_per_launch"] == int(b2)
+        assert d["single_stream"]["solves_per_sec"] < o["solves_per_sec"] < d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - 6174168 * 1024 / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert "solve kernel alone" in r["kernel_ms_brackets"] and r["kernel"] == "solve_kernel_wave2"
+    assert r["traffic"] and r["traffic"] < 2 * 8531784 * 1.2  # PMC bytes per launch close to the compulsory figure
+    v = r["valu_issue"]
+    assert 0.3 < v["frac"] < 1.0 and abs(v["frac"] - v["busy_cycles_per_solve"] * d["value"] / (1024 * 2.4e9)) < 1e-6
+    assert 5e5 < v["insts_per_solve"] < 8e5 and 0.5 < v["throughput"]["frac_of_bound"] < 1.0
+    for chains in ("64", "512"):
+        p = d["pt"][chains]
+        assert p["chains"] == int(chains) and p["ms_per_iteration"] > 0 and p["collectives_per_iteration"] <= 1.0
+        assert abs(p["proposals_per_sec"] - int(chains) / (p["ms_per_iteration"] * 1e-3)) < 1e-6 * p["proposals_per_sec"]
+        assert len(p["max_integrator_steps_per_rank"]) == 1
+    assert d["pt"]["64"]["cpu_baseline"]["kind"] == "port"
+    acc = d["accuracy"]
+    assert acc["all_ok"] is True and max(acc["max_rel_err_per_decade_0_to_8"]) < 1e-6
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "solves/s" and c["value"] > 0
+    # ... and config 5 has a line of its own, on the SPIKE kernel
+    c5 = json.loads(open(path.replace("bench_config2", "bench_config5")).read().strip().splitlines()[-1])
+    assert c5["config"]["nx"] == 512 and c5["config"]["all_solves_ok"] is True and "spike" in c5["roofline"]["kernel"]
+    assert c5["single_stream"]["solves_per_sec"] < c5["value"]
