@@ -41,9 +41,16 @@ struct SpikeBackendT {
     static constexpr bool kParksSamples = true;  // out_sample() parks, out_flush() emits
     static constexpr int NI = W - 1;       // interfaces
     static constexpr int NIF = 4 * NI;     // scalar interface unknowns
-    // this wave's block slab: the 20 rows of WaveBackendT<true> + the two spikes
-    enum { BINV_E = 0, BIA_E, BIC_E, CR_AL, CR_GA, PAL0, PGA0 = PAL0 + 6, NBLK = PGA0 + 6,
-           BFIN = NBLK, ECO0, ECO1, VSPK, WSPK, NROWS };
+    // This wave's block slab, 19 rows of 16 bytes per lane (with the workgroup's shared 4 KB: 80 KB at W = 4, two
+    // workgroups fill a CU's 160 KB exactly):
+    //   the in-lane cyclic reduction (5), al / ga of PCR levels 0-4 (10), ONE row for level 5 -- at stride 32 the lower
+    //   half of the wave has no row below (al = 0) and the upper half none above (ga = 0) --, the last diagonal inverse,
+    //   and the two spikes as V and Z = I + V + W (see build()).  The field back-substitution needs no row: its four
+    //   coefficients per edge are c Lam mv (mu E / 2 -+ D/dx), rebuilt from qE = c Lam mv E (a register).  (The spikes
+    //   as eight bf16 in one row: the weighted norms punish an absolute error of 4e-3 |V xl| in the components a
+    //   Beer-Lambert profile keeps five decades below the surface -- Newton failed on every thin film.)
+    enum { BINV_E = 0, BIA_E, BIC_E, CR_AL, CR_GA, PAL0, PGA0 = PAL0 + 5, L5ROW = PGA0 + 5, BFIN, VSPK, ZSPK, NROWS };
+    static_assert(NROWS == 19, "19 rows per wave");
     static constexpr int kSlabBytes = NROWS * 64 * 16;  // per wave
     // shared by the workgroup: ping-pong exchange buffer [2][W][2][KX] doubles (what a wave's first / last lane
     // publish), the coefficient tables [W][4][NIF]
@@ -58,6 +65,8 @@ struct SpikeBackendT {
     int L, lane, wave, tid;
     Emitter em;
     double w[2][2], mvv[2], cd;
+    float kdn, kdp;  // c Lam D_n / dx, c Lam D_p / dx (wave-uniform)
+    float qE[2];     // c Lam mv E of this lane's two edges (0 on edge 0 and on padded edges)
     void *lds;      // this wave's slab
     double *xb;     // exchange buffer
     double *tab;    // this wave's coefficient table [4][NIF]
@@ -306,9 +315,13 @@ struct SpikeBackendT {
             Lm[r] = ej.lm;
             Rm[r] = ej.rm;
             w[r][0] = ej.w0; w[r][1] = ej.w1;
-            static_cast<float4 *>(lds)[(ECO0 + r) * 64 + lane] = float4{(float)ej.e0, (float)ej.e2, (float)ej.e1, (float)ej.e3};
+            // the four coefficients of the field back-substitution, e0, e1 = c Lam mv (mu_n E / 2 -+ D_n/dx) and
+            // e2, e3 = c Lam mv (mu_p E / 2 +- D_p/dx), are rebuilt from ONE number per edge where they are used
+            qE[r] = (i > 0 && i < L) ? (float)(cL * ej.mv * E) : 0.0f;
             mvv[r] = ej.mv;
         }
+        kdn = (float)(cL * dnx);
+        kdp = (float)(cL * dpx);
         cd = c * p.idx;
         // edge matrices of the next thread's first edge; across a wave boundary from the halo (the same expression
         // the owner evaluates)
@@ -385,8 +398,12 @@ struct SpikeBackendT {
                 Vm = mshf(Vr, lm_); Vp = mshf(Vr, lp_); Wm = mshf(Wr, lm_); Wp = mshf(Wr, lp_);
             }
             const M2 al = mmul(Ak, Bim), ga = mmul(Ck, Bip);
-            put(PAL0 + lv, al);
-            put(PGA0 + lv, ga);
+            if (lv < 5) {
+                put(PAL0 + lv, al);
+                put(PGA0 + lv, ga);
+            } else {
+                put(L5ROW, msel(lane < 32, ga, al));  // (al = 0 where lane < 32, ga = 0 where lane >= 32)
+            }
             Vr = msub(msub(Vr, mmul(al, Vm)), mmul(ga, Vp));
             Wr = msub(msub(Wr, mmul(al, Wm)), mmul(ga, Wp));
             Bk = msub(msub(Bk, mmul(al, Ckm)), mmul(ga, Akp));
@@ -396,8 +413,15 @@ struct SpikeBackendT {
         const M2 Bfin = minv(Bk);
         put(BFIN, Bfin);
         const M2 Vk = mmul(Bfin, Vr), Wk = mmul(Bfin, Wr);
-        put(VSPK, Vk);
-        put(WSPK, Wk);
+        {
+            // NOT (V, W): in a stiff step I + V + W is tiny (the smooth mode of a wave's 128 nodes is nearly harmonic: what
+            // it is at the two ends, it is inside) and 3 digits of V and W are no digits of that -- the re-solve diverged on
+            // the thin film.  (V, Z = I + V + W):  x = g + xf - Z xf - V (xl - xf); the two products are small where the
+            // cancellation was.
+            const M2 Zk{1.0 + Vk.a + Wk.a, Vk.b + Wk.b, Vk.c + Wk.c, 1.0 + Vk.d + Wk.d};
+            put(VSPK, Vk);
+            put(ZSPK, Zk);
+        }
         // ---- the reduced system: every wave publishes its spikes at its first and last row ----
         {
             double hf[8], hl[8];
@@ -502,38 +526,30 @@ struct SpikeBackendT {
         const v2f r0_up{edge_ ? (float)r0ux : r0wx, edge_ ? (float)r0uy : r0wy};
         const v2f t = pb_acc(cr_ga, r0_up, pb_acc(cr_al, r0, v2f(0.0f)));
         v2f rk32 = narrow(V2{r[1].x - (double)t.x, r[1].y - (double)t.y});
-        PB b_inv = al, b_ia = al, b_ic = al, b_fin = al, e0 = al, e1 = al, vs = al, ws = al;
+        PB b_inv = al, b_ia = al, b_ic = al, b_fin = al, b5 = al;
+        PB vs_ = al, zs_ = al;
 #pragma unroll
-        for (int lv = 0; lv < 6; ++lv) {
+        for (int lv = 0; lv < 5; ++lv) {
             const int s = 1 << lv;
             PB al_n = al, ga_n = ga;
-            if (lv < 5) {
+            if (lv < 4) {
                 al_n = get_pb(PAL0 + lv + 1);
                 ga_n = get_pb(PGA0 + lv + 1);
-            }
-            if (lv == 3) {
-                vs = get_pb(VSPK);
-                ws = get_pb(WSPK);
-            } else if (lv == 4) {
+            } else {
+                b5 = get_pb(L5ROW);
                 b_fin = get_pb(BFIN);
+            }
+            if (lv == 2) {
+                vs_ = get_pb(VSPK);
+                zs_ = get_pb(ZSPK);
+            } else if (lv == 3) {
                 b_inv = get_pb(BINV_E);
-            } else if (lv == 5) {
-                b_ia = get_pb(BIA_E);
-                b_ic = get_pb(BIC_E);
-                e0 = get_pb(ECO0);
-                e1 = get_pb(ECO1);
             }
             const v2f rf = rk32;
             v2f rm, rp;
             if (lv == 0) {
                 rm = v2f{from_prev(rf.x), from_prev(rf.y)};
                 rp = v2f{from_next(rf.x), from_next(rf.y)};
-            } else if (lv == 5) {
-                float mx, px, my, py;
-                swap32(rf.x, mx, px);
-                swap32(rf.y, my, py);
-                rm = v2f{mx, my};
-                rp = v2f{px, py};
             } else {
                 rm = v2f{shf(rf.x, (lane - s) & 63), shf(rf.y, (lane - s) & 63)};
                 rp = v2f{shf(rf.x, (lane + s) & 63), shf(rf.y, (lane + s) & 63)};
@@ -542,6 +558,16 @@ struct SpikeBackendT {
             al = al_n;
             ga = ga_n;
         }
+        {  // stride 32: one block per lane, the partner 32 lanes above (lower half) or below (upper half)
+            b_ia = get_pb(BIA_E);
+            b_ic = get_pb(BIC_E);
+            float mx, px, my, py;
+            swap32(rk32.x, mx, px);
+            swap32(rk32.y, my, py);
+            const v2f r5{lane < 32 ? px : mx, lane < 32 ? py : my};
+            rk32 = rk32 - (b5.bd * v2f(r5.y) + b5.ac * v2f(r5.x));
+        }
+        const PB vs = vs_, zs = zs_;
         const v2f g32 = pb_acc(b_fin, rk32, v2f(0.0f));  // this wave's solution with the couplings cut
         // ---- interface solve ----
         {
@@ -564,21 +590,31 @@ struct SpikeBackendT {
         done();
         const v2f xl{(float)lane_value(acc, 0), (float)lane_value(acc, 1)};
         const v2f xf{(float)lane_value(acc, 2), (float)lane_value(acc, 3)};
-        const v2f xk32 = g32 - pb_acc(ws, xf, pb_acc(vs, xl, v2f(0.0f)));
+        const v2f xk32 = (g32 + xf) - pb_acc(zs, xf, pb_acc(vs, xl - xf, v2f(0.0f)));
         const float xpwx = pinned(from_prev(xk32.x)), xpwy = pinned(from_prev(xk32.y));
         // lane 0: the previous wave's last row (wave 0: meets a zero block)
         const v2f xkp32{lane == 0 ? xl.x : xpwx, lane == 0 ? xl.y : xpwy};
         const v2f se = pb_acc(b_inv, r0, v2f(0.0f)) - pb_acc(b_ic, xk32, pb_acc(b_ia, xkp32, v2f(0.0f)));
         x[0] = (double)se.x; x[1] = (double)xk32.x; x[2] = (double)se.y; x[3] = (double)xk32.y;
+        // field back-substitution: (e0, e1) = ea -+ c Lam mv D_n/dx, (e2, e3) = ep +- c Lam mv D_p/dx; edge 0 and padded
+        // edges have none
+        const bool v0 = tid * R > 0 && tid * R < L, v1 = tid * R + 1 < L;
+        const float kn0 = v0 ? kdn * (float)mvv[0] : 0.0f, kp0 = v0 ? kdp * (float)mvv[0] : 0.0f;
+        const float kn1 = v1 ? kdn * (float)mvv[1] : 0.0f, kp1 = v1 ? kdp * (float)mvv[1] : 0.0f;
+        const float hn = 0.5f * (float)p.mun, hp = 0.5f * (float)p.mup;
+        const float a0 = hn * qE[0], p0_ = hp * qE[0], a1 = hn * qE[1], p1_ = hp * qE[1];
+        const PB e0{v2f{a0 - kn0, p0_ + kp0}, v2f{a0 + kn0, p0_ - kp0}}, e1{v2f{a1 - kn1, p1_ + kp1}, v2f{a1 + kn1, p1_ - kp1}};
         const v2f d0 = e0.ac * xkp32 + e0.bd * se, d1 = e1.ac * se + e1.bd * xk32;
         x[4] = b[4] * mvv[0] - (double)(d0.x + d0.y);
         x[5] = b[5] * mvv[1] - (double)(d1.x + d1.y);
     }
 };
 
-// One workgroup of W waves per solve.  W = 4: one wave per SIMD, one workgroup per CU; W = 2: two workgroups per CU.
+// One workgroup of W waves per solve, on a 256-register budget: two waves per SIMD, i.e. two workgroups per CU at W = 4
+// (2 x 80 KB of LDS) and four at W = 2 -- while one workgroup waits at an exchange the other issues (+31 ... +38 % solves per
+// second over one workgroup per CU, measured with 200 registers of the factorisation still spilled).
 template <int W, bool CT>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) void solve_kernel_spike(
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2, 2))) void solve_kernel_spike(
     const mtrpl_solve_desc *__restrict__ descs, const double *__restrict__ ini, const double *__restrict__ tsteps,
     double *__restrict__ out, int32_t *__restrict__ status, int32_t *__restrict__ stats, int64_t B, SolveTuning tune)
 {
