@@ -127,6 +127,12 @@ struct SpikeBackendT {
     {
         static_cast<float4 *>(lds)[blk * 64 + lane] = float4{(float)m.a, (float)m.c, (float)m.b, (float)m.d};
     }
+    __device__ inline M2 getm(int blk)  // a stored block (fp32, by columns) as fp64
+    {
+        asm volatile("" : "+v"(lds_off));
+        const float4 q = *reinterpret_cast<const float4 *>(static_cast<const char *>(lds) + lds_off + blk * 1024);
+        return M2{(double)q.x, (double)q.z, (double)q.y, (double)q.w};
+    }
     typedef float v2f __attribute__((ext_vector_type(2)));
     struct PB { v2f ac, bd; };
     __device__ inline PB get_pb(int blk)
@@ -323,13 +329,15 @@ struct SpikeBackendT {
         kdn = (float)(cL * dnx);
         kdp = (float)(cL * dpx);
         cd = c * p.idx;
-        // edge matrices of the next thread's first edge; across a wave boundary from the halo (the same expression
-        // the owner evaluates)
-        EdgeJac<double> ejh = edge_jac_interior(p, cL, dnx, dpx, y[R - 1], nfN, y[2 * R - 1], nfP, nfE);
-        if (tid * R + R >= L) ejh = edge_jac_none<double>();
-        const M2 LmW = mpin(mnext(Lm[0])), RmW = mpin(mnext(Rm[0]));
-        const M2 LmNext = msel(lane == 63, ejh.lm, LmW);
-        const M2 RmNext = msel(lane == 63, ejh.rm, RmW);
+        // edge matrices of the next thread's first edge: evaluated HERE from that node's (N, P, E) -- three doubles by a
+        // wave shift, or from the halo across a wave boundary -- instead of shifting the neighbour's two finished 2x2
+        // blocks (and holding a second pair of them for the halo): the same expression on the same operands as the
+        // owner's, fewer live registers in the factorisation
+        const double Nnw = pinned(from_next(y[0])), Pnw = pinned(from_next(y[R])), Enw = pinned(from_next(y[2 * R]));
+        const double Nn = (lane == 63) ? nfN : Nnw, Pn = (lane == 63) ? nfP : Pnw, En = (lane == 63) ? nfE : Enw;
+        EdgeJac<double> ejn = edge_jac_interior(p, cL, dnx, dpx, y[R - 1], Nn, y[2 * R - 1], Pn, En);
+        if (tid * R + R >= L) ejn = edge_jac_none<double>();
+        const M2 LmNext = ejn.lm, RmNext = ejn.rm;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = tid * R + r;
@@ -351,56 +359,51 @@ struct SpikeBackendT {
                 B[r] = mident<double>();
             }
         }
-        // in-lane cyclic reduction: row e = 2*tid (r=0) eliminated, row k = 2*tid+1 (r=1) kept
+        // in-lane cyclic reduction: row e = 2*tid (r=0) eliminated, row k = 2*tid+1 (r=1) kept.  (Written so that each of
+        // the next thread's three blocks is consumed where it arrives.)
         const M2 Binv_e = minv(B[0]);
         put(BINV_E, Binv_e);
         put(BIA_E, mmul(Binv_e, A[0]));
         put(BIC_E, mmul(Binv_e, C[0]));
-        {
-            double hf[12], hl[1] = {0.0};
-            m2_to(Binv_e, hf); m2_to(A[0], hf + 4); m2_to(C[0], hf + 8);
-            publish(hf, hl);
+        if (lane == 0) {
+            double *q = slot(wave, 0);
+            m2_to(Binv_e, q); m2_to(A[0], q + 4); m2_to(C[0], q + 8);
         }
+        wg_barrier();
         const double *nq = next_first();
-        const M2 BinvW = mpin(mnext(Binv_e)), AW = mpin(mnext(A[0])), CW = mpin(mnext(C[0]));
-        const M2 Binv_up = msel(lane == 63, m2_of(nq), BinvW);
-        const M2 A_up = msel(lane == 63, m2_of(nq + 4), AW);
-        const M2 C_up = msel(lane == 63, m2_of(nq + 8), CW);
+        M2 Ak, Bk, Ck;
+        {
+            const M2 Binv_up = msel(lane == 63, m2_of(nq), mpin(mnext(Binv_e)));
+            const M2 cr_ga = mmul(C[1], Binv_up);  // (the very last thread: C[1] = 0, whatever Binv_up is)
+            put(CR_GA, cr_ga);
+            const M2 C_up = msel(lane == 63, m2_of(nq + 8), mpin(mnext(C[0])));
+            Ck = mneg(mmul(cr_ga, C_up));
+            const M2 A_up = msel(lane == 63, m2_of(nq + 4), mpin(mnext(A[0])));
+            Bk = msub(B[1], mmul(cr_ga, A_up));
+        }
         done();
-        const M2 cr_al = mmul(A[1], Binv_e);
-        const M2 cr_ga = mmul(C[1], Binv_up);  // (the very last thread: C[1] = 0, whatever Binv_up is)
-        put(CR_AL, cr_al);
-        put(CR_GA, cr_ga);
-        M2 Ak = mneg(mmul(cr_al, A[0]));
-        M2 Ck = mneg(mmul(cr_ga, C_up));
-        M2 Bk = msub(msub(B[1], mmul(cr_al, C[0])), mmul(cr_ga, A_up));
-        // cut the couplings across the wave boundaries; they become the right-hand sides of the two spikes
+        {
+            const M2 cr_al = mmul(A[1], Binv_e);
+            put(CR_AL, cr_al);
+            Ak = mneg(mmul(cr_al, A[0]));
+            Bk = msub(Bk, mmul(cr_al, C[0]));
+        }
+        // Cut the couplings across the wave boundaries: they are the right-hand sides of the two spikes.  The spikes ride
+        // through the factorisation in fp64 next to Bk, Ak, Ck: the interface system they define is nearly singular in a
+        // stiff step (I + V + W -> 0 for the smooth mode), so its entries need the exact factors -- a second pass through
+        // the fp32-STORED factors (tried: 23 spilled registers instead of 200) is off by 6e-4 at the wave's ends, 60 times
+        // the margin, and Newton crawls.  What keeps the registers down instead: levels 1-4 are a REAL loop (unrolled, the
+        // scheduler hoists the exchanges of all levels and both spike columns: 200 spilled registers on this budget).
         M2 Vr = msel(lane == 0 && wave > 0, Ak, mzero<double>());
         M2 Wr = msel(lane == 63 && wave < W - 1, Ck, mzero<double>());
         Ak = msel(lane == 0, mzero<double>(), Ak);
         Ck = msel(lane == 63, mzero<double>(), Ck);
-        // wave-local parallel cyclic reduction over this wave's 64 kept rows, the two spike columns riding along
-#pragma unroll
-        for (int lv = 0; lv < 6; ++lv) {
-            const int s = 1 << lv;
-            const int lm_ = (lane - s) & 63, lp_ = (lane + s) & 63;
-            const M2 Bi = minv(Bk);
-            M2 Bim, Bip, Akm, Akp, Ckm, Ckp, Vm, Vp, Wm, Wp;
-            if (lv == 0) {
-                Bim = mprev(Bi); Bip = mnext(Bi); Akm = mprev(Ak); Akp = mnext(Ak); Ckm = mprev(Ck); Ckp = mnext(Ck);
-                Vm = mprev(Vr); Vp = mnext(Vr); Wm = mprev(Wr); Wp = mnext(Wr);
-            } else if (lv == 5) {
-                mswap32(Bi, Bim, Bip); mswap32(Ak, Akm, Akp); mswap32(Ck, Ckm, Ckp);
-                mswap32(Vr, Vm, Vp); mswap32(Wr, Wm, Wp);
-            } else {
-                Bim = mshf(Bi, lm_); Bip = mshf(Bi, lp_); Akm = mshf(Ak, lm_); Akp = mshf(Ak, lp_);
-                Ckm = mshf(Ck, lm_); Ckp = mshf(Ck, lp_);
-                Vm = mshf(Vr, lm_); Vp = mshf(Vr, lp_); Wm = mshf(Wr, lm_); Wp = mshf(Wr, lp_);
-            }
+        auto level = [&](int lv, const M2 &Bim, const M2 &Bip, const M2 &Akm, const M2 &Akp, const M2 &Ckm, const M2 &Ckp,
+                         const M2 &Vm, const M2 &Vp, const M2 &Wm, const M2 &Wp) {
             const M2 al = mmul(Ak, Bim), ga = mmul(Ck, Bip);
             if (lv < 5) {
-                put(PAL0 + lv, al);
-                put(PGA0 + lv, ga);
+                static_cast<float4 *>(lds)[(PAL0 + lv) * 64 + lane] = float4{(float)al.a, (float)al.c, (float)al.b, (float)al.d};
+                static_cast<float4 *>(lds)[(PGA0 + lv) * 64 + lane] = float4{(float)ga.a, (float)ga.c, (float)ga.b, (float)ga.d};
             } else {
                 put(L5ROW, msel(lane < 32, ga, al));  // (al = 0 where lane < 32, ga = 0 where lane >= 32)
             }
@@ -409,15 +412,31 @@ struct SpikeBackendT {
             Bk = msub(msub(Bk, mmul(al, Ckm)), mmul(ga, Akp));
             Ak = mneg(mmul(al, Akm));
             Ck = mneg(mmul(ga, Ckp));
+        };
+        {   // level 0: nearest neighbours by DPP wave shifts
+            const M2 Bi = minv(Bk);
+            level(0, mprev(Bi), mnext(Bi), mprev(Ak), mnext(Ak), mprev(Ck), mnext(Ck), mprev(Vr), mnext(Vr), mprev(Wr), mnext(Wr));
+        }
+#pragma unroll 1
+        for (int lv = 1; lv < 5; ++lv) {
+            const int lm_ = (lane - (1 << lv)) & 63, lp_ = (lane + (1 << lv)) & 63;
+            const M2 Bi = minv(Bk);
+            level(lv, mshf(Bi, lm_), mshf(Bi, lp_), mshf(Ak, lm_), mshf(Ak, lp_), mshf(Ck, lm_), mshf(Ck, lp_), mshf(Vr, lm_),
+                  mshf(Vr, lp_), mshf(Wr, lm_), mshf(Wr, lp_));
+        }
+        {   // level 5: stride 32 by v_permlane32_swap
+            const M2 Bi = minv(Bk);
+            M2 Bim, Bip, Akm, Akp, Ckm, Ckp, Vm, Vp, Wm, Wp;
+            mswap32(Bi, Bim, Bip); mswap32(Ak, Akm, Akp); mswap32(Ck, Ckm, Ckp); mswap32(Vr, Vm, Vp); mswap32(Wr, Wm, Wp);
+            level(5, Bim, Bip, Akm, Akp, Ckm, Ckp, Vm, Vp, Wm, Wp);
         }
         const M2 Bfin = minv(Bk);
         put(BFIN, Bfin);
         const M2 Vk = mmul(Bfin, Vr), Wk = mmul(Bfin, Wr);
         {
-            // NOT (V, W): in a stiff step I + V + W is tiny (the smooth mode of a wave's 128 nodes is nearly harmonic: what
-            // it is at the two ends, it is inside) and 3 digits of V and W are no digits of that -- the re-solve diverged on
-            // the thin film.  (V, Z = I + V + W):  x = g + xf - Z xf - V (xl - xf); the two products are small where the
-            // cancellation was.
+            // NOT (V, W) as bf16 in one row, and stored as (V, Z = I + V + W): in a stiff step I + V + W is tiny (the
+            // smooth mode of a wave's 128 nodes is nearly harmonic: what it is at the two ends, it is inside);
+            // x = g + xf - Z xf - V (xl - xf) keeps the two products small where the cancellation is.
             const M2 Zk{1.0 + Vk.a + Wk.a, Vk.b + Wk.b, Vk.c + Wk.c, 1.0 + Vk.d + Wk.d};
             put(VSPK, Vk);
             put(ZSPK, Zk);
@@ -434,59 +453,61 @@ struct SpikeBackendT {
         // elimination keeps the shape: D'_j = [[I, Q_j], [Vf_{j+1}, I]], Q_j = Wl_j - Vl_j (E_{j-1})_lf Wf_j,
         // E_j = D'_j^-1 = [[I + Q S Vf, -Q S], [-S Vf, S]], S = (I - Vf Q)^-1.  Lane m (< NIF) carries the unit
         // right-hand side e_m, so it ends up with column m of the inverse; lanes >= NIF compute a zero column.
-        M2 Q[NI], S[NI], Vf[NI], Vl[NI], Wf[NI];
-        V2 hl_[NI], hf_[NI];  // right-hand sides (l-part, f-part) of pair j
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const double *a = slot(j, 1), *b = slot(j + 1, 0);
-            Vl[j] = m2_of(a);          // V_last(j): acts on l_{j-1}
-            const M2 Wl = m2_of(a + 4);  // W_last(j): acts on f_{j+1}
-            Vf[j] = m2_of(b);          // V_first(j+1): acts on l_j
-            Wf[j] = m2_of(b + 4);      // W_first(j+1): acts on f_{j+2}
-            Q[j] = Wl;
-            if (j > 0) {
-                // (E_{j-1})_lf = -Q_{j-1} S_{j-1};  Q_j = Wl_j + Vl_j Q_{j-1} S_{j-1} Wf_{j-1}
-                Q[j] = msub(Wl, mneg(mmul(mmul(Vl[j], mmul(Q[j - 1], S[j - 1])), Wf[j - 1])));
-            }
-            S[j] = minv(msub(mident<double>(), mmul(Vf[j], Q[j])));
-            hl_[j] = V2{(lane == 4 * j) ? 1.0 : 0.0, (lane == 4 * j + 1) ? 1.0 : 0.0};
-            hf_[j] = V2{(lane == 4 * j + 2) ? 1.0 : 0.0, (lane == 4 * j + 3) ? 1.0 : 0.0};
-        }
+        // The published spikes are read where they are needed (that buffer stays put until every wave has passed the
+        // next barrier), Q_j and S_j wait for the back substitution in this wave's own slots of the other buffer.
+        const int pb = xpar;
         done();
-        // forward sweep: h'_j = h_j - L_j E_{j-1} h'_{j-1}: only the l-part changes, by Vl_j (E_{j-1} h'_{j-1})_l
+        double *qs_ = slot(wave, 0);  // 8 NI <= 24 doubles
+        auto pub = [&](int wv, int which) { return xb + ((pb * W + wv) * 2 + which) * KX; };
         V2 el[NI], ef[NI];  // E_j h'_j
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            if (j > 0) {
-                const V2 t = mvec(Vl[j], el[j - 1]);
-                hl_[j] = V2{hl_[j].x - t.x, hl_[j].y - t.y};
+        {
+            M2 Qp = mzero<double>(), Sp = mident<double>(), Wfp = mzero<double>();
+#pragma unroll 1
+            for (int j = 0; j < NI; ++j) {  // (a real loop, like the spike columns above: one interface at a time)
+                const double *a = pub(j, 1), *b = pub(j + 1, 0);
+                const M2 Vl = m2_of(a);      // V_last(j): acts on l_{j-1}
+                const M2 Wl = m2_of(a + 4);  // W_last(j): acts on f_{j+1}
+                const M2 Vf = m2_of(b);      // V_first(j+1): acts on l_j
+                M2 Q = Wl;
+                if (j > 0) Q = msub(Wl, mneg(mmul(mmul(Vl, mmul(Qp, Sp)), Wfp)));  // Q_j = Wl_j + Vl_j Q_{j-1} S_{j-1} Wf_{j-1}
+                const M2 S = minv(msub(mident<double>(), mmul(Vf, Q)));
+                if (lane == 0) {
+                    m2_to(Q, qs_ + 8 * j);
+                    m2_to(S, qs_ + 8 * j + 4);
+                }
+                V2 hl_{(lane == 4 * j) ? 1.0 : 0.0, (lane == 4 * j + 1) ? 1.0 : 0.0};
+                const V2 hf_{(lane == 4 * j + 2) ? 1.0 : 0.0, (lane == 4 * j + 3) ? 1.0 : 0.0};
+                if (j > 0) {  // h'_j = h_j - L_j E_{j-1} h'_{j-1}: only the l-part changes, by Vl_j (E_{j-1} h'_{j-1})_l
+                    const V2 t = mvec(Vl, el[j - 1]);
+                    hl_ = V2{hl_.x - t.x, hl_.y - t.y};
+                }
+                // E h = [hl + Q S (Vf hl - hf) ; S (hf - Vf hl)]
+                const V2 vh = mvec(Vf, hl_);
+                const V2 sf = mvec(S, V2{hf_.x - vh.x, hf_.y - vh.y});
+                const V2 qsv = mvec(Q, sf);
+                el[j] = V2{hl_.x - qsv.x, hl_.y - qsv.y};
+                ef[j] = sf;
+                Qp = Q;
+                Sp = S;
+                Wfp = m2_of(b + 4);  // W_first(j+1): acts on f_{j+2}
             }
-            // E h = [hl + Q S (Vf hl - hf) ; S (hf - Vf hl)]
-            const V2 vh = mvec(Vf[j], hl_[j]);
-            const V2 sf = mvec(S[j], V2{hf_[j].x - vh.x, hf_[j].y - vh.y});
-            const V2 qs = mvec(Q[j], sf);
-            el[j] = V2{hl_[j].x - qs.x, hl_[j].y - qs.y};
-            ef[j] = sf;
         }
-        // back substitution: u_j = E_j h'_j - E_j U_j u_{j+1};  E_j U_j u = [-Q S Wf f_{j+2} ; S Wf f_{j+2}]
-        V2 ul[NI], uf[NI];
-#pragma unroll
-        for (int j = NI - 1; j >= 0; --j) {
-            ul[j] = el[j];
-            uf[j] = ef[j];
-            if (j < NI - 1) {
-                const V2 sw = mvec(S[j], mvec(Wf[j], uf[j + 1]));
-                const V2 qsw = mvec(Q[j], sw);
-                ul[j] = V2{ul[j].x + qsw.x, ul[j].y + qsw.y};
-                uf[j] = V2{uf[j].x - sw.x, uf[j].y - sw.y};
-            }
-        }
+        // back substitution: u_j = E_j h'_j - E_j U_j u_{j+1};  E_j U_j u = [-Q S Wf f_{j+2} ; S Wf f_{j+2}];
         // rows this wave needs: x_last(wave-1) = l_{wave-1}, x_first(wave+1) = f_{wave+1} = f-part of pair `wave`
-        V2 xl{0.0, 0.0}, xf{0.0, 0.0};
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            if (j == wave - 1) xl = ul[j];
-            if (j == wave) xf = uf[j];
+        V2 xl{0.0, 0.0}, xf{0.0, 0.0}, ufn{0.0, 0.0};
+#pragma unroll 1
+        for (int j = NI - 1; j >= 0; --j) {
+            V2 ul = el[j], uf = ef[j];
+            if (j < NI - 1) {
+                const M2 Q = m2_of(qs_ + 8 * j), S = m2_of(qs_ + 8 * j + 4), Wf = m2_of(pub(j + 1, 0) + 4);
+                const V2 sw = mvec(S, mvec(Wf, ufn));
+                const V2 qsw = mvec(Q, sw);
+                ul = V2{ul.x + qsw.x, ul.y + qsw.y};
+                uf = V2{uf.x - sw.x, uf.y - sw.y};
+            }
+            if (j == wave - 1) xl = ul;
+            if (j == wave) xf = uf;
+            ufn = uf;
         }
         if (lane < NIF) {
             tab[0 * NIF + lane] = xl.x;

@@ -46,7 +46,7 @@ if "SQ_WAVES" in sq:
                       "scalar_active_fraction_of_wave_cycles": frac("SQ_ACTIVE_INST_SCA"),
                       "parked_on_waitcnt_fraction_of_wave_cycles": frac("SQ_WAIT_ANY"),
                       "issue_stall_fraction_of_wave_cycles": frac("SQ_WAIT_INST_ANY"),
-                      "occupancy_waves_per_simd": 2 if "wave2" in kern else (1 if "wave" in kern or "team" in kern or "spike" in kern else None),
+                      "occupancy_waves_per_simd": 2 if ("wave2" in kern or "spike" in kern) else (1 if "wave" in kern or "team" in kern or "spike" in kern else None),
                       "wave_cycles_per_solve(quad-cycles*4)": 4 * sq.get("SQ_WAVE_CYCLES", 0) / w / res["waves_per_solve"]}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
