@@ -35,9 +35,9 @@ def run(a, rank, world, local, dev):
     d_ini = torch.from_numpy(ini).to(dev)
     d_t = torch.from_numpy(t_host).to(dev)
     # The K timed steps are independent batches, issued the way bench.py's headline issues them: round-robin on S HIP
-    # streams (a solve holds its CU from start to finish -- 93 KB of LDS: one workgroup per CU, 256 resident -- and step
-    # counts spread 1 : 1.7, so a 512-solve launch alone leaves the CUs its short solves free idle for 40 % of its
-    # time; the next launch's workgroups take them).  `single_stream`: the same K steps one launch at a time.
+    # streams (a solve holds its half of a CU from start to finish -- 80 KB of LDS: two workgroups per CU, 512 resident --
+    # and step counts spread 1 : 1.8, so a 512-solve launch alone leaves the slots its short solves free idle for a
+    # third of its time; the next launch's workgroups take them).  `single_stream`: the same K steps one launch at a time.
     S = max(1, min(int(getattr(a, "streams", 4)), 4))
     outs = [(torch.zeros(B * nt, dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.int32, device=dev),
              torch.zeros(B * 8, dtype=torch.int32, device=dev)) for _ in range(S)]
@@ -106,7 +106,7 @@ def run(a, rank, world, local, dev):
         "single_stream": {"solves_per_sec": world * B * a.steps / single[0], "ms_per_step": single[0] / a.steps * 1e3,
                           "kernel_ms": single[1], "all_solves_ok": single[2],
                           "note": "the same K steps back to back on one stream: every 512-solve launch alone on the device "
-                                  "(two rounds of 256 resident solves)"},
+                                  "(all 512 solves resident, two workgroups per CU)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "solve_kernel_team<double, 4, false, false, true>" if team else "solve_kernel_spike<4, true>",
@@ -115,7 +115,6 @@ def run(a, rank, world, local, dev):
                                        "frac": A * B / (single[1] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                      "device": {"achieved": A * B / (dt / a.steps) / 1e9, "frac": A * B / (dt / a.steps) / 1e9 / HBM_PEAK_GBS},
                      "note": "state-streaming model of SURVEY.md 8d (24.6 MB per nx=512 solve); the state lives in registers "
-                             "and the elimination blocks in LDS (93 KB per workgroup, one workgroup per CU), so HBM is not "
-                             "the limiter: four waves per solve on 256 CUs = 256 solves resident, the rest of the batch "
-                             "queues behind them"},
+                             "and the elimination blocks in LDS (80 KB per workgroup, two workgroups per CU), so HBM is not "
+                             "the limiter: four waves per solve, 512 solves resident on 256 CUs"},
     }
