@@ -172,6 +172,7 @@ def _pt_leg(rank, world, local, dev, with_cpu, use_dist=False):
                 "prefetch": ln["config"]["prefetch"], "chain_groups": ln["config"]["chain_groups"],
                 "collectives_per_iteration": ln["config"].get("collectives_per_iteration"),
                 "max_integrator_steps_per_rank": ln["config"].get("max_integrator_steps_per_rank"),
+                **({"host_ms": ln["config"]["host_ms"]} if "host_ms" in ln["config"] else {}),
                 **({"cpu_baseline": ln["cpu_baseline"]} if "cpu_baseline" in ln else {})}
 
     # (with a process group the warm-up spans two replica exchanges: the first collective of each shape sets RCCL up)
@@ -269,6 +270,10 @@ def main():
                     help="--workload pt: chain groups that run between two replica exchanges at their own pace, one "
                          "HIP stream each (the launch of one overlaps the host work of the other); 0 = 2 where a "
                          "rank's chain block leaves SIMDs idle (the prefetching regime), else 1")
+    ap.add_argument("--decide", default="device", choices=["device", "host"],
+                    help="--workload pt, prefetching: where a launch's accept / reject decisions are taken -- on the device, "
+                         "behind the launch on its stream (the host prepares the next launch's four possible proposal "
+                         "sets while it runs), or on the host between two launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=4,
                     help="issue successive steps round-robin on this many HIP streams, so that the next batch fills "
@@ -359,7 +364,7 @@ def main():
     outs = [(torch.zeros(B * nt, dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.int32, device=dev),
              torch.zeros(B * 8, dtype=torch.int32, device=dev)) for _ in range(S)]
     d_out, d_status, d_stats = outs[0]
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
+    streams = [torch.cuda.current_stream()] + L.shared_streams(dev, S - 1)
     torch.cuda.synchronize()
 
     def step(k=0):

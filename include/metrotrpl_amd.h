@@ -172,6 +172,14 @@ const char *mtrpl_version(void);
  *                                     re-solve (the exact linear algebra; agrees with the default inside the
  *                                     accuracy gate, not bitwise); 1 team kernel (the one traps and nx > 128 use).
  *                                     (4 / 5, round 2's wave-pair kernels, and pair_max_batch are gone: -> MTRPL_ERR_BAD_ARG)
+ *   loglik_wave_blocks                0 (default): mtrpl_loglik_batch_dev runs twelve wavefronts and up to 159 KB of
+ *                                     LDS per trace.  1: launches with nT >= 32 run ONE wavefront and the IRF work space
+ *                                     (9 KB at 189 taps) per block, per-sample arrays in device memory -- a block that
+ *                                     fits wherever a single solve wavefront has left, for a likelihood launch that
+ *                                     shares the device with another stream's queued solves (a twelve-wave block waits
+ *                                     until that queue has drained); the same table bit for bit (with 32 and more
+ *                                     temperatures no sum depends on the block size), the launch alone on the device
+ *                                     takes longer
  *   precision                         64 (product) | 32 (fp32 instantiation of the team kernel: precision sweep only) */
 int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value);
 int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value);
@@ -280,6 +288,29 @@ int mtrpl_loglik_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_like_desc *d_d
                            const double *d_sig, const double *d_tsteps, const double *d_exp_t,
                            const double *d_exp_y, const double *d_exp_u, const double *d_T,
                            int32_t nT, int32_t max_nt, double *d_ll, void *stream);
+
+/* ---- parallel tempering: a launch's decisions taken where its log-likelihoods are -------------------------------
+ * (the Metropolis rule of metropolis.py:42-63 for a chain block.  A launch evaluates, per chain, n_props proposals:
+ * 1 -- y1 for iteration k+1 -- or, prefetching, 3 -- y1, y2r for k+2 from the current state, y2a for k+2 from y1.
+ * The caller -- metrotrpl_amd/pt.py:_DecidePipe -- prepares the next launch's descriptors for every outcome (two /
+ * four) while the launch runs, so that no launch waits for the host between two replica exchanges.)
+ *
+ * mtrpl_pt_decide_dev, for chain i of c, own ladder slot col[i], row row[i] of the block's current table:
+ *     L_g = tab[g, i, col[i]]               tab [n_props, c, nT]: the proposals' rows, summed over the measurements
+ *     a1  = u[0, i] < exp(L_0 - cur_ll[i])  (a NaN ratio rejects, metropolis.py:49-51)
+ *     a2  = n_props == 3 && u[1, i] < exp((a1 ? L_2 : L_1) - (a1 ? L_0 : cur_ll[i]))
+ *     cur_ll[i], cur_tab[row[i], 0..nT) <- the log-likelihood / the row of the state the decisions leave
+ *     outcome[i] = a1 + 2 a2;  result [4, c] = outcome, L_0, L_1, L_2 (what the host needs to follow the chain)
+ * mtrpl_pt_select_dev: next [n_rows, bytes_per_row] <- cand [n_cand, n_rows, bytes_per_row] at
+ *     outcome[chain_of_row[r]] (n_cand = 1: the first launch after an exchange, nothing else read; else the
+ *     outcomes in the order s, y1[, y2r, y2a]); a row is one mtrpl_solve_desc, in whatever order the launch
+ *     issues them.
+ * Everything is device memory; both only enqueue on `stream`. */
+int mtrpl_pt_decide_dev(mtrpl_ctx *ctx, int32_t c, int32_t nT, int32_t n_props, const double *d_tab,
+                        const int32_t *d_col, const int32_t *d_row, const double *d_u, double *d_cur_ll,
+                        double *d_cur_tab, int32_t *d_outcome, double *d_result, void *stream);
+int mtrpl_pt_select_dev(mtrpl_ctx *ctx, int64_t n_rows, int32_t n_cand, int64_t bytes_per_row, const void *d_cand,
+                        const int32_t *d_chain_of_row, const int32_t *d_outcome, void *d_next, void *stream);
 
 #ifdef __cplusplus
 }

@@ -42,7 +42,7 @@ def run(a, rank, world, local, dev):
     outs = [(torch.zeros(B * nt, dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.int32, device=dev),
              torch.zeros(B * 8, dtype=torch.int32, device=dev)) for _ in range(S)]
     d_out, d_status, d_stats = outs[0]
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
+    streams = [torch.cuda.current_stream()] + L.shared_streams(dev, S - 1)
 
     def step(q=0):
         o, st_, sa_ = outs[q]

@@ -450,17 +450,18 @@ __device__ inline void block_sum3(double &a, double &b, double &c, double *sv)
 // One trace: everything the block needs sits behind the pointers it is given.  `work` holds the
 // per-sample arrays (6*max_nt doubles: times, signal, slopes, compared signal, 2u^2, run table), `irfw` the
 // IRF work space (moment table + its prefix sums); the kernel below decides which of them are LDS.
+template <int BLK>
 __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, const double *__restrict__ sig,
                                     const double *__restrict__ tsteps, const double *__restrict__ exp_t,
                                     const double *__restrict__ exp_y, const double *__restrict__ exp_u,
                                     const double *__restrict__ temps, int nT, int max_nt,
                                     const double *__restrict__ tables, const IrfTableSet &set, double neg_frac_tol,
                                     double *__restrict__ ll, double *work, double *irfw, double *red_v,
-                                    int64_t *red_i, int *s_cnt)
+                                    int64_t *red_i, int *s_cnt, int stage_doubles)
 {
     const int nt = ds.nt, n_exp = ds.n_exp, tid = threadIdx.x;
     if (nt > max_nt || n_exp > max_nt || n_exp > nt || nt < 2 || n_exp < 1) {  // caller broke its promise
-        for (int j = tid; j < nT; j += kLikeBlock) ll[sidx * nT + j] = __builtin_nan("");
+        for (int j = tid; j < nT; j += BLK) ll[sidx * nT + j] = __builtin_nan("");
         return;
     }
     double *st = work;            // [nt] simulation times
@@ -469,9 +470,9 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
     double *sol = sb + nt;        // [n_exp] signal at the experimental times; later err^2
     double *su2 = sol + n_exp;    // [n_exp] 2*unc^2
     double *wk = irfw;            // IRF work space: T[3nk], P0,Q0,P1[nk+1]
-    for (int i = tid; i < nt; i += kLikeBlock) { st[i] = tsteps[ds.t_off + i]; sy[i] = sig[ds.sig_off + i]; }
+    for (int i = tid; i < nt; i += BLK) { st[i] = tsteps[ds.t_off + i]; sy[i] = sig[ds.sig_off + i]; }
     __syncthreads();
-    for (int i = tid; i < nt - 1; i += kLikeBlock) sb[i] = (sy[i + 1] - sy[i]) / (st[i + 1] - st[i]);
+    for (int i = tid; i < nt - 1; i += BLK) sb[i] = (sy[i + 1] - sy[i]) / (st[i + 1] - st[i]);
     const double *et = exp_t + ds.exp_off, *ey = exp_y + ds.exp_off, *eu = exp_u + ds.exp_off;
     int n_c = n_exp;  // number of compared samples
     bool failed = false;
@@ -480,7 +481,7 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
         const double *Tg = tables + set.off[ds.irf];
         double *T = wk, *P0 = T + 3 * nk, *Q0 = P0 + (nk + 1), *P1 = Q0 + (nk + 1);
         int *jlo = reinterpret_cast<int *>(su2 + n_exp), *jhi = jlo + nt;  // run table, 2*nt ints
-        for (int i = tid; i < 3 * nk; i += kLikeBlock) T[i] = Tg[i];
+        for (int i = tid; i < 3 * nk; i += BLK) T[i] = Tg[i];
         __syncthreads();
         if (tid < 3) {  // prefix sums of the moment table (sequential: same rounding every time)
             double a = 0.0;
@@ -502,13 +503,13 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
         c.n_r = (int64_t)ceil((c.t_end + set.dt[ds.irf] / 4) / c.half_dt);
         c.nkk = (c.n_r - 1) / 2;  // last convolved index
         if (c.n_r >= (int64_t)1 << 30) {  // index arithmetic below is 32-bit (a 2000 ns trace at 0.025 ns has n_r = 160 001)
-            for (int j = tid; j < nT; j += kLikeBlock) ll[sidx * nT + j] = __builtin_nan("");
+            for (int j = tid; j < nT; j += BLK) ll[sidx * nT + j] = __builtin_nan("");
             return;
         }
         const int64_t nkk = c.nkk, n_r = c.n_r;
         const double half_dt = c.half_dt, t_end = c.t_end;
         c.jlo = jlo; c.jhi = jhi;
-        for (int q = tid; q < nt - 1; q += kLikeBlock) conv_runs(c, q, jlo[q], jhi[q]);
+        for (int q = tid; q < nt - 1; q += BLK) conv_runs(c, q, jlo[q], jhi[q]);
         __syncthreads();
         // ---- pass A: argmax of the convolved trace (laplace.py:82) ----
         // The outputs are walked in chunks, and the walk stops as soon as no later output can still win.
@@ -522,7 +523,7 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
         // trace are never computed.  A NaN sample keeps the bound NaN and the walk complete; a NaN output found
         // ends it (np.argmax returns the first NaN).
         double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-        for (int m = tid; m < nk; m += kLikeBlock) { w0 += fabs(T[3 * m]); w1 += fabs(T[3 * m + 1]); w2 += fabs(T[3 * m + 2]); }
+        for (int m = tid; m < nk; m += BLK) { w0 += fabs(T[3 * m]); w1 += fabs(T[3 * m + 1]); w2 += fabs(T[3 * m + 2]); }
         block_sum3(w0, w1, w2, red_v);
         const double wy = w0 * (1.0 + 1e-9), ws = half_dt * (2.0 * w1 + 4.0 * w2) * (1.0 + 1e-9);
         double best = 0.0;
@@ -531,13 +532,13 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
             // outputs interleaved over the threads: neighbouring lanes work on neighbouring k, so their
             // windows share the runs (LDS broadcasts) and their prefix-sum indices are consecutive
             // (conflict-free); the run pointer still only moves forward per thread
-            constexpr int64_t kChunk = 2 * kLikeBlock;
+            constexpr int64_t kChunk = 2 * BLK;
             int qh = conv_run_of(c, (tid - nk > 0) ? tid - nk : 0);
             for (int64_t k0 = 0; k0 <= nkk; k0 += kChunk) {
                 if (k0 > 0) {
                     const double t_lo = (k0 > nk) ? (double)(2 * (k0 - nk)) * half_dt * (1.0 - 1e-12) : 0.0;
                     double ymax = 0.0, smax = 0.0;
-                    for (int i = tid; i < nt; i += kLikeBlock) {
+                    for (int i = tid; i < nt; i += BLK) {
                         if (st[i + 1 < nt ? i + 1 : i] >= t_lo) {
                             const double a = fabs(sy[i]);
                             ymax = (a > ymax || a != a) ? a : ymax;
@@ -552,7 +553,7 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
                     if (ymax * wy + smax * ws < bmax) break;                // the same decision in every thread
                 }
                 const int64_t k_end = (k0 + kChunk <= nkk) ? k0 + kChunk : nkk + 1;
-                for (int64_t k = k0 + tid; k < k_end; k += kLikeBlock) {
+                for (int64_t k = k0 + tid; k < k_end; k += BLK) {
                     const double acc = conv_fast2(c, k, qh);
                     if (argmax_better(acc, k, best, bi, nkk + 1)) { best = acc; bi = k; }
                 }
@@ -565,7 +566,7 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
         if (ct_last == 0.0 || best != best) failed = true;  // laplace.py:83-84, :76-77
         // ---- post_conv_trim (laplace.py:120-124): exp_t < max(conv_t) ----
         int cnt = 0;
-        for (int i = tid; i < n_exp; i += kLikeBlock) cnt += (et[i] < ct_last) ? 1 : 0;
+        for (int i = tid; i < n_exp; i += BLK) cnt += (et[i] < ct_last) ? 1 : 0;
         if (tid == 0) s_cnt[0] = 0;
         __syncthreads();
         atomicAdd(&s_cnt[0], cnt);
@@ -574,7 +575,7 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
         n_c = s_cnt[0];
         if (n_c == 0) failed = true;  // np.where(...)[0][-1] raises IndexError in the reference
         // ---- pass B: re-interpolate onto the experimental times (laplace.py:121) ----
-        for (int i = tid; i < n_c; i += kLikeBlock) {
+        for (int i = tid; i < n_c; i += BLK) {
             const double te = et[i];
             double v;
             if (!(te >= ct_first && te <= ct_last)) {
@@ -599,31 +600,31 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
         }
     } else {
         // trial_move_evaluation.py:98-101: sol = sol[-len(times_c):]
-        for (int i = tid; i < n_exp; i += kLikeBlock) sol[i] = sy[nt - n_exp + i];
+        for (int i = tid; i < n_exp; i += BLK) sol[i] = sy[nt - n_exp + i];
     }
     __syncthreads();
     // ---- trial_move_evaluation.py:117-130: negative-fraction check, flip ----
     int neg = 0;
-    for (int i = tid; i < n_c; i += kLikeBlock) neg += (sol[i] < 0) ? 1 : 0;
+    for (int i = tid; i < n_c; i += BLK) neg += (sol[i] < 0) ? 1 : 0;
     if (tid == 0) s_cnt[1] = 0;
     __syncthreads();
     atomicAdd(&s_cnt[1], neg);
     __syncthreads();
     if (!((double)s_cnt[1] < neg_frac_tol * (double)n_c)) failed = true;
-    for (int i = tid; i < n_c; i += kLikeBlock)
+    for (int i = tid; i < n_c; i += BLK)
         if (sol[i] < 0) sol[i] *= -1;  // :130
     if (ds.force_min_y) {
         // utils.py:16-31 (set_min_y): min_y = 10 ** min(vals - scale_shift);
         // i_final = np.searchsorted(-sol, -min_y); sol[i_final:] = min_y
         double vmin = __builtin_inf();
-        for (int i = tid; i < n_c; i += kLikeBlock) vmin = fmin(vmin, ey[i] - ds.scale_shift);
+        for (int i = tid; i < n_c; i += BLK) vmin = fmin(vmin, ey[i] - ds.scale_shift);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmin = fmin(vmin, __shfl_xor(vmin, o, 64));
         __syncthreads();
         if ((tid & 63) == 0) red_v[tid >> 6] = vmin;
         __syncthreads();
         double vm = red_v[0];
-        for (int w = 1; w < kLikeWaves; ++w) vm = fmin(vm, red_v[w]);
+        for (int w = 1; w < (BLK / 64); ++w) vm = fmin(vm, red_v[w]);
         const double min_y = pow(10.0, vm);
         if (tid == 0) {
             int lo = 0, hi = n_c;  // lower_bound of -min_y in -sol, exactly numpy's bisection
@@ -636,12 +637,12 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
         __syncthreads();
         const int i_final = s_cnt[0];
         __syncthreads();
-        for (int i = tid; i < n_c; i += kLikeBlock)
+        for (int i = tid; i < n_c; i += BLK)
             if (i >= i_final) sol[i] = min_y;
         __syncthreads();
     }
     // ---- :147-156: err_sq and ll(T) = -sum err_sq / (sigma^2 T + 2 u^2) ----
-    for (int i = tid; i < n_c; i += kLikeBlock) {
+    for (int i = tid; i < n_c; i += BLK) {
         const double s = sol[i];
         const double e = (log10(s) + ds.scale_shift - ey[i]);
         sol[i] = e * e;
@@ -656,7 +657,7 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
         double *parts = irfw;  // [nT][kLadderSplit] -- when that fits in the 6*nk+3 doubles of the IRF work space
         const bool fits = ds.irf >= 0 && (size_t)nT * kLadderSplit <= 6 * (size_t)set.nk[ds.irf];
         if (fits) {
-            for (int u = tid; u < nT * kLadderSplit; u += kLikeBlock) {
+            for (int u = tid; u < nT * kLadderSplit; u += BLK) {
                 const int j = u / kLadderSplit, r = u - j * kLadderSplit;
                 const double sT = sg2 * temps[j];
                 double tot = 0.0;
@@ -664,7 +665,7 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
                 parts[u] = tot;
             }
             __syncthreads();
-            for (int j = tid; j < nT; j += kLikeBlock) {
+            for (int j = tid; j < nT; j += BLK) {
                 double tot = 0.0;
                 for (int r = 0; r < kLadderSplit; ++r) tot += parts[j * kLadderSplit + r];
                 tot = -tot;
@@ -672,27 +673,52 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
                 ll[sidx * nT + j] = tot;
             }
         } else {
-            for (int j = tid; j < nT; j += kLikeBlock) {
-                const double sT = sg2 * temps[j];
-                double tot = 0.0;
-                for (int i = 0; i < n_c; ++i) tot += sol[i] * frcp1(sT + su2[i]);
-                tot = -tot;
-                if (failed || tot != tot) tot = -__builtin_inf();
-                ll[sidx * nT + j] = tot;
+            const double *e2 = sol, *u2 = su2;
+            if (2 * n_c <= stage_doubles) {
+                // (one-wave blocks keep their per-sample arrays in device memory: every thread walks all samples here,
+                // so they move into the LDS the IRF work space no longer needs)
+                for (int i = tid; i < n_c; i += BLK) { irfw[i] = sol[i]; irfw[n_c + i] = su2[i]; }
+                __syncthreads();
+                e2 = irfw;
+                u2 = irfw + n_c;
+            }
+            // one thread per temperature, its samples in order; a thread that owns several temperatures (a small block
+            // under a long ladder) walks the samples once for all of them: independent chains for the reciprocals
+            constexpr int KT = (BLK >= 256) ? 1 : 8;
+            for (int j0 = tid; j0 < nT; j0 += BLK * KT) {
+                double sT[KT], tot[KT];
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    const int j = j0 + k * BLK;
+                    sT[k] = sg2 * temps[j < nT ? j : nT - 1];
+                    tot[k] = 0.0;
+                }
+                for (int i = 0; i < n_c; ++i) {
+                    const double e = e2[i], u = u2[i];
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) tot[k] += e * frcp1(sT[k] + u);
+                }
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    const int j = j0 + k * BLK;
+                    double t = -tot[k];
+                    if (failed || t != t) t = -__builtin_inf();
+                    if (j < nT) ll[sidx * nT + j] = t;
+                }
             }
         }
     } else {
         for (int j = 0; j < nT; ++j) {
             const double sT = sg2 * temps[j];
             double part = 0.0;
-            for (int i = tid; i < n_c; i += kLikeBlock) part += sol[i] / (sT + su2[i]);
+            for (int i = tid; i < n_c; i += BLK) part += sol[i] / (sT + su2[i]);
             part = wave_sum(part);
             __syncthreads();
             if ((tid & 63) == 0) red_v[tid >> 6] = part;
             __syncthreads();
             if (tid == 0) {
                 double tot = 0.0;
-                for (int w = 0; w < kLikeWaves; ++w) tot += red_v[w];
+                for (int w = 0; w < (BLK / 64); ++w) tot += red_v[w];
                 tot = -tot;
                 if (failed || tot != tot) tot = -__builtin_inf();
                 ll[sidx * nT + j] = tot;
@@ -701,14 +727,17 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
     }
 }
 
-// One 768-thread block per (chain, measurement) while the per-sample arrays fit in LDS (GWORK = false:
+// One BLK-thread block (768: twelve waves) per (chain, measurement) while the per-sample arrays fit in LDS (GWORK = false:
 // 48 bytes per sample, 3400 samples in 160 KB next to a 189-tap IRF).  Longer traces -- real TRPL files
 // run to tens of thousands of samples, and the reference has no limit (trial_move_evaluation.py:96-158)
 // -- keep only the IRF work space in LDS and put the per-sample arrays in a per-block slab of global
 // memory (GWORK = true; L2-resident, written and read by this block only), blocks striding over the
-// traces.
-template <bool GWORK>
-__global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_desc *__restrict__ descs,
+// traces.  BLK = 64 (GWORK only, nT >= 32 -- there no sum depends on the block size: the same numbers bit for bit):
+// one wave per block and 9 KB of LDS, a block that fits wherever ONE solve wave has left -- for likelihood launches
+// that share the device with another stream's queued solves, where a twelve-wave block with 57 KB of LDS waits
+// until that queue has drained.
+template <bool GWORK, int BLK>
+__global__ __launch_bounds__(BLK) void loglik_kernel(const mtrpl_like_desc *__restrict__ descs,
                                                             const double *__restrict__ sig,
                                                             const double *__restrict__ tsteps,
                                                             const double *__restrict__ exp_t,
@@ -717,24 +746,24 @@ __global__ __launch_bounds__(kLikeBlock) void loglik_kernel(const mtrpl_like_des
                                                             const double *__restrict__ temps, int nT, int max_nt,
                                                             const double *__restrict__ tables, IrfTableSet set,
                                                             double neg_frac_tol, double *__restrict__ ll, int64_t B,
-                                                            double *__restrict__ gwork)
+                                                            double *__restrict__ gwork, int stage_doubles)
 {
     extern __shared__ double smem[];
-    __shared__ double red_v[3 * kLikeWaves];
-    __shared__ int64_t red_i[kLikeWaves];
+    __shared__ double red_v[3 * (BLK / 64)];
+    __shared__ int64_t red_i[(BLK / 64)];
     __shared__ int s_cnt[2];
     double *work = GWORK ? gwork + (size_t)blockIdx.x * 6 * (size_t)max_nt : smem;
     double *irfw = GWORK ? smem : smem + 6 * (size_t)max_nt;
     if (!GWORK) {  // one block per trace
         const int64_t sidx = blockIdx.x;
         if (sidx < B)
-            loglik_trace(descs[sidx], sidx, sig, tsteps, exp_t, exp_y, exp_u, temps, nT, max_nt, tables, set, neg_frac_tol,
-                         ll, work, irfw, red_v, red_i, s_cnt);
+            loglik_trace<BLK>(descs[sidx], sidx, sig, tsteps, exp_t, exp_y, exp_u, temps, nT, max_nt, tables, set, neg_frac_tol,
+                         ll, work, irfw, red_v, red_i, s_cnt, 0);
         return;
     }
     for (int64_t sidx = blockIdx.x; sidx < B; sidx += gridDim.x) {
-        loglik_trace(descs[sidx], sidx, sig, tsteps, exp_t, exp_y, exp_u, temps, nT, max_nt, tables, set, neg_frac_tol,
-                     ll, work, irfw, red_v, red_i, s_cnt);
+        loglik_trace<BLK>(descs[sidx], sidx, sig, tsteps, exp_t, exp_y, exp_u, temps, nT, max_nt, tables, set, neg_frac_tol,
+                     ll, work, irfw, red_v, red_i, s_cnt, stage_doubles);
         __syncthreads();
     }
 }

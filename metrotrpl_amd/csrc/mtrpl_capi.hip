@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <deque>
@@ -53,6 +54,7 @@ struct mtrpl_ctx {
     int precision = 64;      // 64: fp64 (the product); 32: the fp32 build of the team kernel (precision sweep only)
     size_t like_lds_attr = 64 * 1024;  // dynamic-LDS limit the likelihood kernel has been raised to
     unsigned long long call_id = 0;
+    int loglik_wave_blocks = 0;  // 1: likelihood launches with nT >= 32 run one wave per block (see include/metrotrpl_amd.h)
     int two_per_simd_min_batch = 1025;  // kernel_variant 0: launches of at least this many std / nx <= 128 solves use
                                         // the two-solves-per-SIMD build of the wave kernel (more than one solve per
                                         // SIMD anyway), smaller ones the one-per-SIMD build: same results
@@ -521,6 +523,8 @@ int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value)
         // removed in round 2 (the Jacobian is always refreshed at a refactorisation): accepted and ignored
     } else if (k == "two_per_simd_min_batch") {
         ctx->two_per_simd_min_batch = (int)value;
+    } else if (k == "loglik_wave_blocks") {
+        ctx->loglik_wave_blocks = value != 0;
     } else if (k == "precision") {
         if (value != 32 && value != 64) return bad(ctx, MTRPL_ERR_BAD_ARG, "precision must be 32 or 64");
         ctx->precision = (int)value;
@@ -540,6 +544,7 @@ int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value)
         if (k == o.key) { *value = ctx->tune.*(o.m); return MTRPL_OK; }
     if (k == "kernel_variant") *value = ctx->kernel_variant;
     else if (k == "two_per_simd_min_batch") *value = ctx->two_per_simd_min_batch;
+    else if (k == "loglik_wave_blocks") *value = ctx->loglik_wave_blocks;
     else if (k == "precision") *value = ctx->precision;
     else if (k == "fresh_jac") *value = 0.0;  // accepted and ignored (set_option)
     else return MTRPL_ERR_BAD_ARG;
@@ -837,6 +842,7 @@ int mtrpl_calculate_photoc(mtrpl_ctx *ctx, int64_t n, const double *N, const dou
 }
 
 #include "irf_capi.inc"
+#include "pt_capi.inc"
 
 #ifdef MTRPL_TRACE
 extern "C" int mtrpl_debug_trace(float *out, int *n)

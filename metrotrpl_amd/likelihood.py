@@ -75,6 +75,7 @@ class LikelihoodEngine:
         self.sort_by_cost = bool(sort_by_cost)
         self.parts = max(1, int(parts))
         self.split_min, self.sort_min = int(split_min), int(sort_min)
+        self._stage = []  # pinned staging buffers of the descriptor upload: [tensor, event] pairs, used in turn
         self._side = []
         self._cap = 0
         self._tmpl = {}
@@ -182,6 +183,17 @@ class LikelihoodEngine:
         self._cuts = cuts
         return d, ini_arr, ld
 
+    def _row_cost(self, n):
+        """Residency of every solve in the previous launch, row for row (chain-major order); None when the previous
+        launch had another size or was not ordered (its residencies were not copied back)."""
+        prev = getattr(self, "_prev_order", None)
+        if prev is None or prev.shape[0] != n or self._ticks is None or self._ticks[1] != n:
+            return None
+        self._ticks[2].synchronize()
+        cost = np.empty(n)
+        cost[prev] = self._ticks[0][:n].numpy()
+        return cost if np.any(cost > 0) else None
+
     def _measured_cost(self, n, states):
         """Residency of every solve in the previous launch (stats[7]), in chain-major order: Metropolis
         proposals are small moves, so the last iteration's cost is the best predictor of this one's.  A
@@ -231,11 +243,92 @@ class LikelihoodEngine:
             tm["dev_" + key] = self.torch.from_numpy(raw).to(self.dev)
         return tm["dev_" + key]
 
+    def _to_device(self, raw):
+        """The descriptor array through a pinned staging buffer, asynchronously on the current stream (a copy from
+        pageable memory makes the host wait for the copy engine; two buffers in turn, each behind the event of its
+        last copy)."""
+        torch = self.torch
+        n = raw.shape[0]
+        if len(self._stage) < 2:
+            self._stage.append([torch.empty(max(n, 1 << 16), dtype=torch.uint8, pin_memory=True), None])
+            slot = self._stage[-1]
+        else:
+            slot = self._stage[0]
+            self._stage.reverse()
+            if slot[1] is not None:
+                slot[1].synchronize()
+            if slot[0].shape[0] < n:
+                slot[0] = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+        slot[0][:n].numpy()[:] = raw
+        out = torch.empty(n, dtype=torch.uint8, device=self.dev)
+        out.copy_(slot[0][:n], non_blocking=True)
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream())
+        return out
+
+    # ---- packed launches: descriptors the caller keeps (and may choose between) on the device ------------------
+    def plan_packed(self, states):
+        """Fix, for the packed launches of `states.shape[0]` state rows that follow, the order the solves are issued in
+        (`sort_by_cost` / `sort_min`: the residencies of the previous launch of this size, row for row -- the rows of
+        a Metropolis ensemble between two replica exchanges keep their chains -- or, without any, tauP / tauN of
+        `states`) and the split into `parts` streams.  -> the state row of every descriptor row, in issue order."""
+        states = np.atleast_2d(np.asarray(states, dtype=np.float64))
+        R = states.shape[0]
+        n = R * self.M
+        parts = self.parts if n > self.split_min else 1
+        cuts = [(R * p // parts) * self.M for p in range(parts + 1)]
+        order = None
+        if self.sort_by_cost and n > self.sort_min:
+            cost = self._row_cost(n)
+            if cost is None:
+                cost = np.repeat(1.0 + states[:, self.indexes["tauP"]] / states[:, self.indexes["tauN"]], self.M)
+            order = np.concatenate([a + np.argsort(-cost[a:b], kind="stable") for a, b in zip(cuts[:-1], cuts[1:])])
+        self._packed = (n, cuts, order)
+        return (np.arange(n) if order is None else order) // self.M
+
+    def pack_rows(self, states, sets=1):
+        """Solve descriptors of `states` [R, n_params] x M measurements as bytes [R * M, desc size]; `sets` > 1: the
+        rows are that many alternative sets of R / sets state rows, each placed (output and initial-condition offsets)
+        and ordered (`plan_packed`; default: as given, M rows per state row) as if it were launched alone -- for callers
+        that hold several candidate sets on the device and pick rows there (pt.PTEnsemble's device-side decisions).
+        Only for ensembles whose likelihood descriptors and initial-condition array do not depend on the state (no
+        fitted scale factor, no density-mode fittables)."""
+        if self.fit["scale"].max() >= 0 or (self.ini_mode == "density" and max(self.fit["fluences"].max(), self.fit["absps"].max()) >= 0):
+            raise NotImplementedError("packed launches need state-independent likelihood descriptors")
+        keep = self.sort_by_cost, self.parts
+        self.sort_by_cost, self.parts = False, 1
+        try:
+            d, _, _ = self.descriptors(states)
+        finally:
+            self.sort_by_cost, self.parts = keep
+        one = d.shape[0] // sets
+        if sets > 1:
+            for key in ("out_off", "ini_off"):
+                d[key] = np.tile(d[key][:one], sets)
+        plan = getattr(self, "_packed", None)
+        if plan is not None and plan[0] == one and plan[2] is not None:
+            d = d.reshape(sets, one)[:, plan[2]].reshape(-1)
+        return d.view(np.uint8).reshape(d.shape[0], -1)
+
+    def use_packed(self, d_descs, n_solves):
+        """The next `launch` runs the `n_solves` descriptors of the device tensor `d_descs` (bytes, as `pack_rows`
+        lays one set out)."""
+        tm = self._template(n_solves // self.M)
+        self.n_solves, self.d_descs = int(n_solves), d_descs
+        self.d_ini = self._const(tm, "ini_arr", tm["ini_arr"])
+        self.d_like = self._const(tm, "ld", tm["ld"])
+        plan = getattr(self, "_packed", None)
+        if plan is not None and plan[0] == n_solves:
+            self._cuts, self._order = plan[1], plan[2]
+        else:
+            self._cuts, self._order = [0, int(n_solves)], None
+
     def upload(self, states):
         d, ini_arr, ld = self.descriptors(states)
         self.n_solves = d.shape[0]
         tm = self._template(self.n_solves // self.M)
-        self.d_descs = self.torch.from_numpy(d.view(np.uint8).reshape(-1)).to(self.dev)
+        self.d_descs = self._to_device(d.view(np.uint8).reshape(-1))
         self.d_ini = self._const(tm, "ini_arr", ini_arr)
         self.d_like = self._const(tm, "ld", ld)
 
@@ -248,8 +341,9 @@ class LikelihoodEngine:
         lib, h = L.lib(), self.ctx.handle
         cuts = self._cuts
         n_parts = len(cuts) - 1
-        while len(self._side) < n_parts - 1:
-            self._side.append(torch.cuda.Stream(device=self.dev))
+        if len(self._side) < n_parts - 1:
+            self._side = list(reversed(L.shared_streams(self.dev, max(4, n_parts - 1))))[:n_parts - 1]  # from the far end
+            #                  of the process's pool: the streams callers launch engines on come from its near end
         # (the library issues the solves of a launch in the order of the descriptor array: the measured-cost order
         # this engine packed them in is the order they run in)
         fork = None

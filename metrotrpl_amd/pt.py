@@ -29,6 +29,9 @@ bench.py run in) or per iteration (draws in the reference's program order, "stre
 
 Host logic only (numpy + torch.distributed); the evaluator is injected.
 """
+import gc
+import time
+
 import numpy as np
 
 MAX_PROPOSALS = 100  # sim_utils.py:20
@@ -69,7 +72,9 @@ class Proposer:
 
     def approve(self, new_log):
         """True = all checks of approve_move pass; new_log: [C, n] in proposal space (log10 where do_log)."""
-        lin = self.to_lin(new_log)
+        return self._approve(new_log, self.to_lin(new_log))
+
+    def _approve(self, new_log, lin):
         ok = (((self.lo < lin) & (lin < self.hi)) | self.skip).all(axis=1)
         if self.pn is not None:
             ok &= new_log[:, self.pn[0]] > new_log[:, self.pn[1]]
@@ -83,16 +88,27 @@ class Proposer:
     def __call__(self, states, temperatures, rng):
         cur = np.log10(states) if self.all_log else np.where(self.do_log, np.log10(np.where(self.do_log, states, 1.0)), states)
         width = np.sqrt(np.asarray(temperatures))[:, None] * self.base[None, :]
-        new = cur.copy()
-        todo = np.ones(states.shape[0], dtype=bool)
+        out = np.empty_like(cur)
+        todo = None  # rows still without an approved proposal (None: all of them)
         for _ in range(self.rounds):
-            u = rng.random(states.shape)
-            cand = cur + width * (2 * u - 1)
-            new[todo] = cand[todo]
-            todo &= ~self.approve(new)
-            if not todo.any():
-                break
-        return self.to_lin(new)
+            u = rng.random(states.shape)  # every round draws for the whole ensemble; a row uses its own numbers
+            if todo is None:
+                cand = cur + width * (2 * u - 1)
+            else:
+                cand = cur[todo] + width[todo] * (2 * u[todo] - 1)
+            lin = self.to_lin(cand)
+            ok = self._approve(cand, lin)
+            if todo is None:
+                out[:] = lin
+                if ok.all():
+                    break
+                todo = np.flatnonzero(~ok)
+            else:
+                out[todo] = lin  # (a row that fails every round keeps its last draw, trial_move_generation.py:88-96)
+                todo = todo[~ok]
+                if todo.size == 0:
+                    break
+        return out
 
 
 def approve(new_state_log, names, active, prior, do_log, ix):
@@ -122,22 +138,19 @@ def replica_exchange(table, rng):
     temperature k.  Returns (owner, attempts, accepts): owner[k] = index of the
     state that sits at temperature slot k afterwards."""
     n = table.shape[0]
-    owner = np.arange(n)
-    attempts = np.zeros(n, dtype=np.int64)
-    accepts = np.zeros(n, dtype=np.int64)
-    for _ in range(n - 1):
-        i = int(rng.integers(0, n - 1))
-        attempts[i] += 1
-        a, b = owner[i], owner[i + 1]
-        bi_ui, bj_ui = table[a, i], table[a, i + 1]
-        bi_uj, bj_uj = table[b, i], table[b, i + 1]
-        logratio = bi_ui + bj_uj - bi_uj - bj_ui
-        with np.errstate(over="ignore", invalid="ignore"):
-            acc = rng.random() < np.exp(-logratio)
-        if acc:
-            owner[i], owner[i + 1] = b, a
-            accepts[i] += 1
-    return owner, attempts, accepts
+    owner = list(range(n))
+    attempts, accepts = [0] * n, [0] * n
+    item, integers, random, exp = table.item, rng.integers, rng.random, np.exp
+    with np.errstate(over="ignore", invalid="ignore"):
+        for _ in range(n - 1):
+            i = int(integers(0, n - 1))
+            attempts[i] += 1
+            a, b = owner[i], owner[i + 1]
+            logratio = item(a, i) + item(b, i + 1) - item(b, i) - item(a, i + 1)  # bi_ui + bj_uj - bi_uj - bj_ui
+            if random() < exp(-logratio):
+                owner[i], owner[i + 1] = b, a
+                accepts[i] += 1
+    return np.array(owner), np.array(attempts, dtype=np.int64), np.array(accepts, dtype=np.int64)
 
 
 LOCAL_ONLY = object()  # `group` of a ONE-rank ensemble that must not touch the process group it happens to live in (bench.py's
@@ -242,6 +255,18 @@ class _Rows:
         return self.rng.random((self.n,) + tuple(shape[1:]))[self.sel]
 
 
+class _TiledRows(_Rows):
+    """... the same rows once per candidate state of the group, stacked (`_DecidePipe`)."""
+
+    def __init__(self, rng, n, sel, reps):
+        super().__init__(rng, n, sel)
+        self.reps = reps
+
+    def random(self, shape):
+        u = super().random(shape)
+        return np.tile(u, (self.reps,) + (1,) * (u.ndim - 1))
+
+
 class PTEnsemble:
     """One rank's view of the sharded ensemble.
 
@@ -264,11 +289,17 @@ class PTEnsemble:
         `groups` interleaved sets (chain c in group c % groups), each with its own evaluator and HIP stream;
         while the host decides and re-proposes for one group, the other group's launch is on the GPU.
 
+      * device-side decisions (`device_decisions`, evaluators that offer `pack_rows` / `launch_packed`): the accept /
+        reject of a launch, the choice of the next launch's proposals among the sets the host has prepared while
+        the launch ran (one per outcome: two, or four when prefetching) and the update of the table rows all happen
+        on the device, behind the launch on its stream; the host runs one launch ahead and reads the decisions back
+        when it needs the states.  Between two replica exchanges no launch waits for the host (`_DecidePipe`).
+
     In counter mode `states`, `logll` and `table` are complete on every rank after `initialise`, after a
     replica exchange and after `advance` / `sync`; in between a rank keeps only its own rows current."""
 
     def __init__(self, states, temperatures, evaluator, rank=0, world=1, seed=235817049752375780, group=None,
-                 rng_mode="stream", streams=None):
+                 rng_mode="stream", streams=None, device_decisions=False):
         if rng_mode not in ("stream", "counter"):
             raise ValueError("rng_mode must be 'stream' or 'counter'")
         self.states = np.array(states, dtype=np.float64)
@@ -303,6 +334,16 @@ class PTEnsemble:
         self.n_collectives = 0                    # all-gathers issued so far
         self.swap_attempts = np.zeros(self.n, dtype=np.int64)
         self.swap_accepts = np.zeros(self.n, dtype=np.int64)
+        self.prof = None  # a dict: host seconds per phase of the loop (tools/pt_host_phases.py)
+        self.chain_cost = np.zeros(self.n)  # what the evaluator said a chain's last evaluation cost (own rows; 0 = unknown)
+        self.device_decisions = bool(device_decisions)
+        self.n_pipelined = 0  # launches decided on the device so far
+
+    def _tick(self, key, t0):
+        if self.prof is not None:
+            dt = time.perf_counter() - t0
+            self.prof[key] = self.prof.get(key, 0.0) + dt
+            self.prof[key + ".max"] = max(self.prof.get(key + ".max", 0.0), dt)
 
     @property
     def evaluator(self):
@@ -356,9 +397,12 @@ class PTEnsemble:
         import torch.distributed as dist
         if not self.local:
             return
-        for st in self.streams:  # the decisions of every group have been applied to cur_tab on its stream
+        for st in self.streams:  # the decisions of every group have been applied to cur_tab on its side stream
             if st is not None:
                 st.synchronize()
+        for c_ in getattr(self, "_devc", {}).values():
+            if c_.get("side") is not None:
+                c_["side"].synchronize()
         c, nT, npar = self.hi - self.lo, self.T.shape[0], self.states.shape[1]
         dev = self.cur_tab.device
         host = np.concatenate([self.states[self.lo:self.hi], self.acc_count[self.lo:self.hi, None].astype(np.float64)], axis=1)
@@ -394,10 +438,16 @@ class PTEnsemble:
             dev = self.cur_tab.device
             sel = self.own[g]
             pin = dev.type == "cuda"
+            side = c.get(("side", g))
+            if side is None and pin and self.streams[g] is not None:
+                # the accepted rows move into cur_tab on a stream of their own: nothing reads cur_tab before the next
+                # exchange, so that work has no place in front of the group's next launch
+                side = c[("side", g)] = {"side": torch.cuda.Stream(device=dev)}
             c[key] = {"col": torch.from_numpy(np.tile(sel, G)).to(dev),
                       "rows": torch.from_numpy(np.ascontiguousarray(sel - self.lo)).to(dev),
                       "mask_host": torch.zeros((2, max(1, sel.shape[0])), dtype=torch.bool, pin_memory=pin),
-                      "mask_dev": torch.zeros((2, max(1, sel.shape[0])), dtype=torch.bool, device=dev)}
+                      "mask_dev": torch.zeros((2, max(1, sel.shape[0])), dtype=torch.bool, device=dev),
+                      "side": side["side"] if side else None, "side_done": None}
         return c[key]
 
     def _sync_logll(self):
@@ -408,6 +458,7 @@ class PTEnsemble:
         """Propose the next `depth` (1 or 2) iterations of group g and enqueue their evaluation: per chain
         the proposal of iteration it+1 and, for depth 2, the two proposals it+2 can make -- from the current
         state if it+1 rejects, from the it+1 proposal if it accepts."""
+        t0 = time.perf_counter()
         it = self.git[g]
         sel = self.own[g] if self.local else self.sel[g]
         xs, Ts = self.states[sel], self.T[sel]
@@ -422,9 +473,12 @@ class PTEnsemble:
             if self.rng_mode != "counter":
                 raise RuntimeError("prefetching needs rng_mode='counter'")
             props += [proposer(xs, Ts, rows(it + 2)), proposer(y1, Ts, rows(it + 2))] if sel.shape[0] else [xs.copy(), xs.copy()]
+        self._tick("propose", t0)
         if self.local:
+            t0 = time.perf_counter()
             self.pending[g] = (depth, props, _LocalEval(self.evaluators[g], props, self.T, sel, self.streams[g],
                                                         self._dev_cache(g, len(props))))
+            self._tick("enqueue", t0)
             return
         self.n_collectives += int(self._collective())
         gather = TableGather(self.evaluators[g], props, self.T, self.gblocks[g], self.rank, self.world, self.group,
@@ -458,7 +512,10 @@ class PTEnsemble:
         # own block only: the proposals' log-likelihoods at the chains' own temperatures decide; the table rows
         # of the accepted ones replace the current rows ON THE DEVICE
         sel = self.own[g]
+        t0 = time.perf_counter()
         lls = ev.own_ll()  # [depth == 2 ? 3 : 1][c]
+        self._tick("wait", t0)
+        t0 = time.perf_counter()
         a1 = metropolis_accept(self.logll[sel], lls[0], self.draws(it + 1, ACCEPT), (self.n, sel))
         self.states[sel[a1]] = props[0][a1]
         self.logll[sel[a1]] = lls[0][a1]
@@ -473,7 +530,10 @@ class PTEnsemble:
             self.acc_count[sel[a2]] += 1
             accs.append(a2)
             masks.append(a2)
+        self._tick("decide", t0)
+        t0 = time.perf_counter()
         ev.apply(self.cur_tab, sel - self.lo, masks)
+        self._tick("apply", t0)
         self.git[g] = it + depth
         full = []
         for a in accs:  # in the shape the replicated mode returns: one flag per chain of the group (own rows set)
@@ -483,16 +543,24 @@ class PTEnsemble:
         return full
 
     def _exchange(self, it):
+        t0 = time.perf_counter()
+        self._exchange_(it)
+        self._tick("exchange", t0)
+
+    def _exchange_(self, it):
         self.sync()
         owner, att, accs = replica_exchange(self.table, self.draws(it, SWAP))
         self.states = self.states[owner]
         self.table = self.table[owner]
+        self.chain_cost = self.chain_cost[owner]
         self._sync_logll()
         self.swap_attempts += att
         self.swap_accepts += accs
         if self.local:
             import torch
             self.cur_tab.copy_(torch.from_numpy(np.ascontiguousarray(self.table[self.lo:self.hi])))
+            if self.cur_tab.is_cuda:
+                torch.cuda.current_stream().synchronize()  # the groups' streams read and write cur_tab from here on
 
     def _all_groups(self, proposer, depth, do_swap):
         for g in range(self.groups):
@@ -522,17 +590,46 @@ class PTEnsemble:
             raise RuntimeError("iterate2 needs rng_mode='counter'")
         return tuple(self._all_groups(proposer, 2, do_swap))
 
+    def _pipelined(self, proposer, seg_end, depth):
+        """Every whole launch of `depth` iterations up to `seg_end`, for the groups whose evaluator can launch from
+        descriptors kept on the device, with the decisions taken there (`_DecidePipe`); the groups' host work is
+        interleaved."""
+        pipes = []
+        for g in range(self.groups):
+            ev = self.evaluators[g]
+            n_launches = (seg_end - self.git[g]) // depth
+            if n_launches > 0 and hasattr(ev, "pack_rows") and hasattr(ev, "launch_packed"):
+                pipes.append(_DecidePipe(self, g, proposer, n_launches, depth))
+        plans = [p.schedule() for p in pipes]
+        for step in range(max((len(pl) for pl in plans), default=0)):
+            for p, pl in zip(pipes, plans):
+                if step < len(pl):
+                    getattr(p, pl[step][0])(pl[step][1])
+
     def advance(self, proposer, n_iters, temper_freq, prefetch=False):
         """`n_iters` iterations with a replica exchange after every `temper_freq`-th (metropolis.py:129).
         Between two exchanges every chain group runs at its own pace: with `prefetch` two iterations per
         launch, and with several groups the launch of one overlaps the host work of the others.
         -> accepted moves of the whole ensemble (counter mode: `states`, `logll`, `table` are complete again on
         return)."""
+        # (no cyclic garbage collection between two launches: a full collection walks every object of the process --
+        # tens of milliseconds with torch loaded, a dozen launches' worth -- and this loop creates no cycles)
+        gc_was = gc.isenabled()
+        gc.disable()
+        try:
+            return self._advance(proposer, n_iters, temper_freq, prefetch)
+        finally:
+            if gc_was:
+                gc.enable()
+
+    def _advance(self, proposer, n_iters, temper_freq, prefetch):
         n_acc, stop = 0, self.it + n_iters
         acc0 = int(self.acc_count.sum())
         while self.it < stop:
             seg_end = min(stop, (self.it // temper_freq + 1) * temper_freq)  # next exchange or the end
             depth = lambda g: 2 if prefetch and seg_end - self.git[g] >= 2 else 1  # noqa: E731
+            if self.local and self.device_decisions:
+                self._pipelined(proposer, seg_end, 2 if prefetch else 1)  # every whole launch up to seg_end
             queue = [g for g in range(self.groups) if self.git[g] < seg_end]
             for g in queue:
                 self._begin(proposer, g, depth(g))
@@ -550,6 +647,218 @@ class PTEnsemble:
                 self.sync()
             return int(self.acc_count.sum()) - acc0
         return n_acc
+
+
+class _DecidePipe:
+    """Counter mode, one chain group on this rank, from its current iteration through `n_launches` launches of `depth`
+    iterations each (1, or 2: prefetching) with NO host decision between the launches.
+
+    depth 2: launch j evaluates, per chain, the proposal of iteration 2j+1 and the two proposals 2j+2 can make.  Which
+    state it starts from depends on the two decisions of launch j-1 -- four outcomes: (reject, reject) keeps s,
+    (accept, reject) y1, (reject, accept) y2r, (accept, accept) y2a -- and those four states are known on the host as
+    soon as launch j-1 has been PROPOSED.  So while launch j-1 runs the host proposes from all four (stacked: one
+    `proposer` call per draw), packs the four descriptor sets and sends them up; behind launch j-1 on the group's
+    stream sit its decisions (`u < exp(ll_new - ll_cur)`, the uniforms went up with the package), the per-chain pick of
+    the next descriptors, the move of the accepted table rows into `cur_tab`, launch j and the copy of the outcome and
+    the proposals' log-likelihoods per chain to pinned memory.  The host reads the outcome of launch j-2 before it
+    prepares launch j (it needs the actual state s_{j-2}); the device never waits for it.  depth 1: one proposal per
+    chain and launch, two outcomes -- the throughput-bound ensemble, whose launches otherwise wait for the host to
+    decide, propose and pack between them.  Same chain as `_begin` / `_end`, bit for bit, as long as `exp` on the
+    device and in numpy agree on which side of a uniform a ratio lies.
+
+    What the group's evaluator has to offer: `pack_rows(states [R, n_params], sets)` -> descriptor bytes
+    [R * M, B] (`sets` alternative sets of R / sets state rows, each laid out as if launched alone, in the order the
+    evaluator issues them) and `launch_packed(descriptors on the device, n_solves, temperatures)` -> table [R / sets,
+    nT]; optionally `plan_packed(states of one set)` -> the state row of every descriptor row (an evaluator that issues
+    its solves in an order of its own; default: M consecutive rows per state row), `select` / `decide` (the two device
+    steps as one kernel each instead of torch operations) and `row_cost(R)` (cost per state row of the last launch)."""
+
+    def __init__(self, ens, g, proposer, n_launches, depth):
+        import torch
+        self.torch, self.ens, self.g, self.proposer, self.L, self.depth = torch, ens, g, proposer, n_launches, depth
+        self.G = 3 if depth == 2 else 1  # proposals per chain and launch
+        self.ev = ens.evaluators[g]
+        self.stream = ens.streams[g]
+        self.sel = ens.own[g]
+        if hasattr(self.ev, "row_cost") and self.sel.shape[0]:
+            # the chains that were expensive in the last launch go first: launches of two groups share the device, and
+            # what has to wait for a SIMD should be the cheapest solves (the hardware starts workgroups in index order)
+            self.sel = self.sel[np.argsort(-ens.chain_cost[self.sel], kind="stable")]
+        self.c = self.sel.shape[0]
+        self.it0 = ens.git[g]
+        self.s = ens.states[self.sel].copy()  # the state after the last decision the host has read
+        self.Ts = ens.T[self.sel]
+        self.pk = []  # per launch: candidate proposals, pinned buffers, event
+        self.done = 0  # launches whose decisions the host has read
+        self.k_of = {}  # launch -> outcome index (a1 + 2 a2) per chain, once read
+        dev = ens.cur_tab.device
+        self.dev = dev
+        if self.c:
+            c, G = self.c, self.G
+            # the state row (g * c + chain) of every descriptor row of a launch, in the evaluator's issue order
+            if hasattr(self.ev, "plan_packed"):
+                srow = np.asarray(self.ev.plan_packed(np.tile(self.s, (G, 1))), dtype=np.int64)
+            else:
+                srow = None
+            idx = torch.from_numpy(np.stack([self.sel - ens.lo, self.sel]).astype(np.int32)).to(dev)
+            self.row32, self.col32 = idx[0], idx[1]
+            self.rows, self.col = idx[0].long(), idx[1].long()
+            self.fast = hasattr(self.ev, "decide") and hasattr(self.ev, "select")
+            self.srow = srow
+            with self._on():
+                self.cur_ll = ens.cur_tab[self.rows, self.col].clone()  # the chains' log-likelihoods at their own temperatures
+                self.outcome = None
+                self.chain_of_row = None  # built with the first package (the evaluator's M is not known here)
+                if self.fast:
+                    self.outcome = torch.zeros(c, dtype=torch.int32, device=dev)
+                    self.result = torch.zeros((4, c), dtype=torch.float64, device=dev)
+
+    def _on(self):
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else _Nothing()
+
+    def schedule(self):
+        """The host's actions in order: ('enqueue', j) / ('read', j)."""
+        out = [("enqueue", 0)]
+        if self.L > 1:
+            out.append(("enqueue", 1))
+        for j in range(2, self.L):
+            out += [("read", j - 2), ("enqueue", j)]
+        if self.L > 1:
+            out.append(("read", self.L - 2))
+        out.append(("read", self.L - 1))
+        return out
+
+    def _actual(self, j):
+        """The proposals launch j really evaluated [G, c, n_params] (known once launch j-1 has been read)."""
+        pk = self.pk[j]
+        if "actual" not in pk:
+            p = pk["props"]  # [n_cand, G, c, n_params]
+            pk["actual"] = p[0] if p.shape[0] == 1 else np.ascontiguousarray(
+                p[self.k_of[j - 1], :, np.arange(self.c)].transpose(1, 0, 2))
+        return pk["actual"]
+
+    def enqueue(self, j):
+        torch, ens, c, G = self.torch, self.ens, self.c, self.G
+        if c == 0:
+            self.pk.append({})
+            return
+        t0 = time.perf_counter()
+        assert self.done >= j - 1 and len(self.pk) == j
+        if j == 0:
+            cands = self.s[None]
+        else:  # the states launch j-1 can leave behind, from the state the host knows (after launch j-2)
+            cands = np.stack([self.s] + list(self._actual(j - 1)))
+        nc = cands.shape[0]
+        it = self.it0 + self.depth * j
+        S = cands.reshape(nc * c, -1)
+        Tt = np.tile(self.Ts, nc)
+        rows = lambda i: _TiledRows(ens.draws(i, PROPOSE), ens.n, self.sel, nc)  # noqa: E731
+        ys = [self.proposer(S, Tt, rows(it + 1))]
+        u = np.zeros((2, c))
+        u[0] = ens.draws(it + 1, ACCEPT).random(ens.n)[self.sel]
+        if G == 3:
+            ys += [self.proposer(S, Tt, rows(it + 2)), self.proposer(ys[0], Tt, rows(it + 2))]
+            u[1] = ens.draws(it + 2, ACCEPT).random(ens.n)[self.sel]
+        props = np.stack([y.reshape(nc, c, -1) for y in ys], axis=1)  # [nc, G, c, n_params]
+        ens._tick("propose", t0)
+        t0 = time.perf_counter()
+        raw = self.ev.pack_rows(props.reshape(nc * G * c, -1), nc)  # [nc * G c M, B] bytes, each set placed as if alone
+        ens._tick("pack", t0)
+        t0 = time.perf_counter()
+        n_solves = raw.shape[0] // nc
+        nbytes = raw.size
+        pin = self.dev.type == "cuda"
+        key = ("pipe", nbytes + 16 * c)
+        free = _PINNED.setdefault(key, [])
+        stage = free.pop() if free else torch.empty(nbytes + 16 * c, dtype=torch.uint8, pin_memory=pin)
+        stage[:nbytes].numpy()[:] = raw.reshape(-1)
+        stage[nbytes:].numpy()[:] = u.view(np.uint8).reshape(-1)
+        with self._on():
+            if self.chain_of_row is None:
+                M = n_solves // (G * c)
+                srow = self.srow if self.srow is not None else np.repeat(np.arange(G * c), M)
+                self.chain_of_row = torch.from_numpy((srow % c).astype(np.int32)).to(self.dev)
+                self.chain_of_row_l, self.ar = self.chain_of_row.long(), torch.arange(n_solves, device=self.dev)
+            up = torch.empty(nbytes + 16 * c, dtype=torch.uint8, device=self.dev)
+            up.copy_(stage, non_blocking=True)
+            u_dev = up[nbytes:].view(torch.float64)  # [2, c] flat
+            if self.fast:  # the evaluator brings kernels for both steps (pt_bench.setup: mtrpl_pt_select_dev / _decide_dev)
+                d = torch.empty(nbytes // nc, dtype=torch.uint8, device=self.dev)
+                self.ev.select(up[:nbytes], nc, n_solves, self.chain_of_row, self.outcome, d)
+            else:
+                cand_dev = up[:nbytes].view(nc, n_solves, -1)
+                d = cand_dev[0] if nc == 1 else cand_dev[self.outcome[self.chain_of_row_l], self.ar]
+                d = d.contiguous().view(-1)
+            tab = self.ev.launch_packed(d, n_solves, ens.T)  # [G c, nT]
+            if self.fast:
+                self.ev.decide(tab, G, self.col32, self.row32, u_dev, self.cur_ll, ens.cur_tab, self.outcome, self.result)
+                res = self.result
+            else:
+                t = tab.view(G, c, -1)
+                diag = tab.gather(1, self.col.repeat(G)[:, None])[:, 0].view(G, c)
+                a1 = u_dev[:c] < torch.exp(diag[0] - self.cur_ll)  # NaN compares False: rejected, like metropolis_accept
+                cur1 = torch.where(a1, diag[0], self.cur_ll)
+                m1 = a1[:, None]
+                new_rows = torch.where(m1, t[0], ens.cur_tab[self.rows])
+                if G == 3:
+                    ll2 = torch.where(a1, diag[2], diag[1])
+                    a2 = u_dev[c:] < torch.exp(ll2 - cur1)
+                    self.cur_ll = torch.where(a2, ll2, cur1)
+                    self.outcome = a1.long() + 2 * a2.long()
+                    new_rows = torch.where(a2[:, None], torch.where(m1, t[2], t[1]), new_rows)
+                    res = torch.cat([self.outcome.double()[None], diag], dim=0)  # [4, c]
+                else:
+                    self.cur_ll, self.outcome = cur1, a1.long()
+                    res = torch.cat([self.outcome.double()[None], diag, torch.zeros_like(diag), torch.zeros_like(diag)], dim=0)
+                ens.cur_tab[self.rows] = new_rows
+            rkey = ("pipe_res", 4 * c)
+            rfree = _PINNED.setdefault(rkey, [])
+            host = rfree.pop() if rfree else torch.empty((4, c), dtype=torch.float64, pin_memory=pin)
+            host.copy_(res, non_blocking=True)
+            event = None
+            if pin:
+                event = torch.cuda.Event()
+                event.record(self.stream if self.stream is not None else torch.cuda.current_stream())
+        self.pk.append({"props": props, "host": host, "event": event, "stage": (key, stage), "rkey": rkey})
+        ens.n_pipelined += 1
+        ens._tick("enqueue", t0)
+
+    def read(self, j):
+        """The decisions of launch j -> the host's copy of the group's states, log-likelihoods and accept counts."""
+        ens, c = self.ens, self.c
+        assert self.done == j
+        self.done = j + 1
+        if c == 0:
+            ens.git[self.g] += self.depth
+            return
+        pk = self.pk[j]
+        t0 = time.perf_counter()
+        if pk["event"] is not None:
+            pk["event"].synchronize()
+        ens._tick("wait", t0)
+        t0 = time.perf_counter()
+        res = pk["host"].numpy().copy()
+        _PINNED[pk["rkey"]].append(pk["host"])
+        _PINNED[pk["stage"][0]].append(pk["stage"][1])
+        k = np.rint(res[0]).astype(np.int64)
+        a = self._actual(j)  # needs k_of[j - 1]
+        self.k_of[j] = k
+        a1, a2 = (k & 1).astype(bool), (k >> 1).astype(bool)
+        sel = self.sel
+        s, ll = self.s, ens.logll[sel]
+        s = np.where(a1[:, None], a[0], s)
+        ll = np.where(a1, res[1], ll)
+        if self.G == 3:
+            s = np.where(a2[:, None], np.where(a1[:, None], a[2], a[1]), s)
+            ll = np.where(a2, np.where(a1, res[3], res[2]), ll)
+        self.s = s
+        ens.states[sel] = s
+        ens.logll[sel] = ll
+        ens.acc_count[sel] += a1.astype(np.int64) + a2.astype(np.int64)
+        ens.git[self.g] += self.depth
+        if j == self.L - 1 and hasattr(self.ev, "row_cost"):
+            ens.chain_cost[sel] = np.asarray(self.ev.row_cost(self.G * c), dtype=np.float64).reshape(self.G, c).max(axis=0)
+        ens._tick("decide", t0)
 
 
 class _LocalEval:
@@ -595,14 +904,21 @@ class _LocalEval:
 
     def apply(self, cur_tab, rows, masks):
         """cur_tab[rows] <- table row of the accepted proposal: iteration 1 takes props[0] where masks[0]; iteration
-        2 (prefetched) takes props[2] where masks[0] else props[1], where masks[1]."""
+        2 (prefetched) takes props[2] where masks[0] else props[1], where masks[1].  On the group's side stream when
+        it has one (the launch this decides has finished -- its event was waited for -- so the side stream has
+        nothing to wait for; `PTEnsemble.sync` waits for the side streams before anyone reads cur_tab)."""
         import torch
         if self.c == 0:
             return
-        with (torch.cuda.stream(self.stream) if self.stream is not None else _Nothing()):
+        side = self.cache.get("side")
+        st = side if side is not None else self.stream
+        with (torch.cuda.stream(st) if st is not None else _Nothing()):
             mh, md, idx = self.cache["mask_host"], self.cache["mask_dev"], self.cache["rows"]
-            # (the previous launch of this group has been decided, i.e. its mask copy has been consumed: the event
-            # its decision waited for sits behind that copy on the same stream)
+            # (the previous launch of this group has been decided, i.e. its mask copy has been consumed: on the
+            # group's own stream the event its decision waited for sits behind that copy; on the side stream the
+            # event recorded behind the previous apply is waited for here -- it fired a whole launch ago)
+            if self.cache.get("side_done") is not None:
+                self.cache["side_done"].synchronize()
             mh[0, :self.c] = torch.from_numpy(np.ascontiguousarray(masks[0]))
             if len(masks) == 2:
                 mh[1, :self.c] = torch.from_numpy(np.ascontiguousarray(masks[1]))
@@ -613,3 +929,8 @@ class _LocalEval:
             if len(masks) == 2:
                 cur = torch.where(md[1, :self.c, None], torch.where(m1, t[2], t[1]), cur)
             cur_tab[idx] = cur
+            if side is not None:
+                self.dev_tab.record_stream(side)  # allocated on the group's stream, last read here
+                if self.cache.get("side_done") is None:
+                    self.cache["side_done"] = torch.cuda.Event()
+                self.cache["side_done"].record(side)

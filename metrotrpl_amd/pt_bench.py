@@ -9,6 +9,7 @@ chain, n_chains x 6 forward solves + IRF convolutions + likelihoods at all ladde
 temperatures on the GPUs, accept/reject of the rank's own chains, and (every temper_freq
 iterations, SURVEY.md 8d: 10) the all-gather + replica-exchange replay.
 """
+import gc
 import json
 import os
 import time
@@ -49,7 +50,7 @@ def synthetic_data(irf_tables, nx, times):
 
 
 def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=True, split_min=2048, sort_min=1024,
-          ctx=None, force_min_y=False, groups=1):
+          ctx=None, force_min_y=False, groups=1, packed_order="chains"):
     """The config-3/4 problem on one rank: engine(s), ladder, evaluator(s) and proposer.  groups > 1: one
     engine, evaluator and HIP stream per chain group of pt.PTEnsemble."""
     import torch
@@ -66,15 +67,50 @@ def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=Tr
                                {"TRPL": 1.0}, np.array(W.STAUB_FLUENCES), ini_mode="fluence", irf_tables=irf_tables,
                                irf_convolution=[745] * 6, device=local, ctx=ctx, sort_by_cost=sort_by_cost, parts=parts,
                                split_min=split_min, sort_min=sort_min, force_min_y=force_min_y)
+        eng.prof = None  # a dict: host seconds spent packing + uploading / enqueuing (tools/pt_host_phases.py)
 
         def evaluator(states_block, temps):
+            t0 = time.perf_counter()
             eng.upload(states_block)
+            t1 = time.perf_counter()
             ll = eng.launch(d_T, len(temps))
-            return ll.view(-1, eng.M, len(temps)).sum(dim=1)
+            tab = ll.view(-1, eng.M, len(temps)).sum(dim=1)
+            if eng.prof is not None:
+                eng.prof["upload"] = eng.prof.get("upload", 0.0) + t1 - t0
+                eng.prof["launch"] = eng.prof.get("launch", 0.0) + time.perf_counter() - t1
+            return tab
+
+        def launch_packed(d_descs, n_solves, temps):
+            eng.use_packed(d_descs, n_solves)
+            return eng.launch(d_T, len(temps)).view(-1, eng.M, len(temps)).sum(dim=1)
+        evaluator.pack_rows, evaluator.launch_packed = eng.pack_rows, launch_packed
+
+        # pt._DecidePipe: the two decisions of a launch and the pick of the next launch's descriptors, one kernel each
+        def select(cand, n_cand, n_rows, chain_of_row, outcome, out):
+            ctx.check(L.lib().mtrpl_pt_select_dev(ctx.handle, n_rows, n_cand, L.SOLVE_DESC_DTYPE.itemsize, cand.data_ptr(),
+                                                  chain_of_row.data_ptr(), outcome.data_ptr(), out.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream))
+
+        def decide(tab, n_props, col, row, u, cur_ll, cur_tab, outcome, result):
+            ctx.check(L.lib().mtrpl_pt_decide_dev(ctx.handle, col.shape[0], tab.shape[1], n_props, tab.data_ptr(),
+                                                  col.data_ptr(), row.data_ptr(), u.data_ptr(), cur_ll.data_ptr(),
+                                                  cur_tab.data_ptr(), outcome.data_ptr(), result.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream))
+        evaluator.select, evaluator.decide = select, decide
+
+        def row_cost(n_rows):  # integrator steps of the slowest of a state row's M solves in the last launch
+            return eng.d_stats[:8 * n_rows * eng.M].view(n_rows, eng.M, 8)[:, :, 0].max(dim=1).values.cpu().numpy()
+        # the order of a packed launch's solves: big launches solve by solve (the engine's measured-cost order and
+        # stream split, fixed per stretch between two exchanges), small ones chain by chain (pt._DecidePipe)
+        if os.environ.get("MTRPL_PT_NO_ORDER") != "1":
+            if packed_order == "solves":
+                evaluator.plan_packed = eng.plan_packed
+            else:
+                evaluator.row_cost = row_cost
         return eng, evaluator
     made = [make(g) for g in range(max(1, groups))]
     engines, evaluators = [m[0] for m in made], [m[1] for m in made]
-    streams = [torch.cuda.Stream(device=dev) for _ in engines] if groups > 1 else None
+    streams = L.shared_streams(dev, len(engines)) if groups > 1 else None  # (the same few streams in every stage)
 
     names = W.PARAM_NAMES
     ix = W.indexes()
@@ -91,7 +127,6 @@ def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=Tr
 
 def run(a, rank, world, local, dev, cpu_baseline_fn=None):
     import torch
-    import torch.distributed as dist
     n_chains = a.chains
     # Prefetching (pt.PTEnsemble.iterate2): when this rank's block leaves most SIMDs idle -- one solve occupies one
     # SIMD for the whole launch -- evaluate iteration k+1's proposals for both outcomes of iteration k in the same
@@ -101,14 +136,46 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
     lo, hi = pt.partition(n_chains, world)[rank]
     mode = getattr(a, "prefetch", "auto")
     prefetch = mode == "on" or (mode == "auto" and (hi - lo) * 6 <= 0.8 * slots)
-    # chain groups (one engine + HIP stream each: the launch of one overlaps the host work and the likelihood
-    # tail of the other): the same latency-bound regime
-    groups = int(getattr(a, "groups", 0)) or (2 if prefetch else 1)
+    # chain groups (one engine + HIP stream each, each walking between two replica exchanges at its own pace).  With the
+    # decisions taken on the device no launch waits for the host, and what several groups buy is that one group's
+    # launch fills the SIMDs the others' slowest solves leave idle: three, in the latency-bound (prefetching) regime
+    # and in the throughput-bound one.  With the decisions on the host: two where the host work of one can hide
+    # behind the launch of the other (prefetching), one otherwise.
+    decide = getattr(a, "decide", "device")
+    groups = int(getattr(a, "groups", 0)) or (3 if decide == "device" else (2 if prefetch else 1))
+    ctx = L.default_context(local)
+    restore = {}
+
+    def set_option(key, value):
+        restore.setdefault(key, ctx.get_option(key))
+        ctx.set_option(key, value)
+    if groups > 1 and not prefetch:
+        # several throughput-bound groups share the device.  Every launch, whatever its size, runs two solves per SIMD;
+        # and a group's likelihood launch has to find room among the other groups' queued solves: blocks of one wave
+        # do, blocks of twelve wait until that queue has drained (include/metrotrpl_amd.h, loglik_wave_blocks)
+        set_option("two_per_simd_min_batch", 1)
+        set_option("loglik_wave_blocks", float(os.environ.get("MTRPL_LL_WAVE", "1")))
     for kv in getattr(a, "opt", []) or []:
         k_, v_ = kv.split("=")
-        L.default_context(local).set_option(k_, float(v_))
+        set_option(k_, float(v_))
+    try:
+        return _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups, decide)
+    finally:
+        for k_, v_ in restore.items():  # the context is the process's default one: other bench legs use it too
+            ctx.set_option(k_, v_)
+
+
+def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups, decide):
+    import torch
+    import torch.distributed as dist
+    # the order the solves of a launch are issued in: the small launches of the prefetching ensemble (launches of a few
+    # hundred solves from several chain groups share 1024 SIMDs: what has to wait for a SIMD should be the cheapest
+    # solves) chain by chain, the throughput-bound launches solve by solve, both by the integrator's cost in the
+    # previous launch
+    small = prefetch and groups > 1
     S = setup(n_chains, dev, local, sort_by_cost=os.environ.get("MTRPL_NO_SORT") != "1",
-              parts=int(os.environ.get("MTRPL_PARTS", "2" if groups == 1 else "1")), groups=groups)
+              parts=int(os.environ.get("MTRPL_PARTS", "2" if groups == 1 else "1")), groups=groups,
+              packed_order="chains" if small else "solves")
     eng, ens0, T, proposer = S["eng"], S["ens0"], S["T"], S["proposer"]
     # history-free draws (pt.PTEnsemble "counter" mode): the chain walked does not depend on N, on prefetching
     # or on the chain groups
@@ -116,11 +183,14 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
     # may happen to live in: bench.py runs such legs on rank 0 of an N-rank job while the other ranks wait
     local_only = world == 1 and not getattr(a, "use_dist", False)
     ens = pt.PTEnsemble(ens0["chain_states"], T, S["evaluators"] if groups > 1 else S["evaluator"], rank=rank,
-                        world=world, rng_mode="counter", streams=S["streams"], group=pt.LOCAL_ONLY if local_only else None)
+                        world=world, rng_mode="counter", streams=S["streams"], group=pt.LOCAL_ONLY if local_only else None,
+                        device_decisions=decide == "device")
     ens.initialise()
     temper_freq = 10
     ens.advance(proposer, a.warmup, temper_freq, prefetch)
     torch.cuda.synchronize()
+    gc.collect()
+    gc.freeze()  # what exists now is not garbage: later full collections do not walk it (torch alone is ~1e6 objects)
     timing = []
     for e_ in S["engines"]:
         e_.timing = timing
@@ -128,6 +198,8 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
         dist.barrier()
     torch.cuda.synchronize()
     coll0 = ens.n_collectives
+    if os.environ.get("MTRPL_PT_PROF") == "1":
+        ens.prof = {}
     t0 = time.perf_counter()
     n_acc = ens.advance(proposer, a.steps, temper_freq, prefetch)
     torch.cuda.synchronize()
@@ -157,6 +229,7 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
                                "(n_T + n_params)] per replica exchange (every 10 iterations)",
                    "chains": n_chains, "solves_per_step": n_chains * 6, "parallelism": f"chain-blocks x{world}",
                    "prefetch": bool(prefetch), "chain_groups": groups,
+                   "decisions": "device" if ens.n_pipelined else "host",
                    "collectives_per_iteration": (ens.n_collectives - coll0) / max(1, a.steps),
                    "forward_solves_per_sec": n_chains * 6 * a.steps / dt, "accepted_moves": n_acc,
                    "swap_accept_rate": float(ens.swap_accepts.sum() / max(1, ens.swap_attempts.sum())),
@@ -164,6 +237,8 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
                    "max_integrator_steps_rank0": int(stats[:, 0].max()),
                    "max_integrator_steps_per_rank": steps_rank},
     }
+    if ens.prof is not None:
+        line["config"]["host_ms"] = {k: round(v * 1e3, 3) for k, v in ens.prof.items()}
     if rank == 0:
         # roofline of the dominant kernel (the forward solve) from the HIP events recorded around every
         # solve launch of the timed iterations, on the stream it was launched on
@@ -173,7 +248,8 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
         n_solve = [n for *_, n in timing]
         kern_ms = float(np.mean(t_solve))
         # launches of more than 1024 solves go to the two-solves-per-SIMD form of the wave kernel (include/metrotrpl_amd.h)
-        kern_name = "solve_kernel_wave2" if float(np.mean(n_solve)) >= 1025 else "solve_kernel_wave1"
+        kern_name = ("solve_kernel_wave2" if float(np.mean(n_solve)) >= L.default_context(local).get_option("two_per_simd_min_batch")
+                     else "solve_kernel_wave1")
         achieved = A * float(np.mean(n_solve)) / (kern_ms * 1e-3) / 1e9
         line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS, "kernel": kern_name, "kernel_ms": kern_ms,

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--prefetch", type=int, default=0)
     ap.add_argument("--groups", type=int, default=1)
     ap.add_argument("--kernel-variant", type=int, default=0)
+    ap.add_argument("--device-decisions", type=int, default=0)
+    ap.add_argument("--packed-order", default="chains")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     import torch
@@ -40,16 +42,26 @@ def main():
     L.default_context(0).set_option("kernel_variant", a.kernel_variant)
     irf_raw = np.load(os.path.join(REPO, "tests", "golden", "irf.npz"))["irf745_raw"]
     S = pt_bench.setup(a.chains, dev, 0, irf_raw=irf_raw, parts=a.parts, sort_by_cost=bool(a.sort), split_min=0,
-                       sort_min=0, force_min_y=bool(a.force_min_y), groups=a.groups)
+                       sort_min=0, force_min_y=bool(a.force_min_y), groups=a.groups, packed_order=a.packed_order)
     ens = pt.PTEnsemble(S["ens0"]["chain_states"], S["T"], S["evaluators"] if a.groups > 1 else S["evaluator"], rank=0,
-                        world=1, rng_mode=a.rng_mode, streams=S["streams"])
+                        world=1, rng_mode=a.rng_mode, streams=S["streams"], device_decisions=bool(a.device_decisions))
     ens.initialise()
     table0 = ens.table.copy()
     n_parts = len(S["eng"]._cuts) - 1
     swaps = a.iters // a.temper_freq
     calls = []
     def spy(inner):
-        return lambda block, temps: (calls.append(block.shape[0]), inner(block, temps))[1]
+        def f(block, temps):
+            calls.append(block.shape[0])
+            return inner(block, temps)
+        if a.device_decisions:  # what pt._DecidePipe looks for
+            hooks = ["pack_rows", "launch_packed", "plan_packed", "row_cost"]
+            if a.device_decisions == 1:  # 2: the torch-op form of the two steps instead of the library's kernels
+                hooks += ["select", "decide"]
+            for k in hooks:
+                if hasattr(inner, k):
+                    setattr(f, k, getattr(inner, k))
+        return f
     ens.evaluators = [spy(ev) for ev in ens.evaluators]
     n_acc = ens.advance(S["proposer"], a.iters, a.temper_freq, prefetch=bool(a.prefetch))
     torch.cuda.synchronize()
@@ -57,7 +69,8 @@ def main():
     np.savez(a.out, states0=S["ens0"]["chain_states"], table0=table0, states=ens.states, logll=ens.logll, table=ens.table,
              swap_attempts=ens.swap_attempts, swap_accepts=ens.swap_accepts, T=S["T"], times=S["times"],
              vals=np.array(S["vals"]), uncs=np.array(S["uncs"]), n_parts=n_parts, swaps=swaps, backend=np.array(backend),
-             ordered=np.array(S["eng"]._order is not None), calls=np.array(calls), n_acc=n_acc, n_collectives=ens.n_collectives)
+             ordered=np.array(S["eng"]._order is not None), calls=np.array(calls), n_acc=n_acc, n_collectives=ens.n_collectives,
+             n_pipelined=ens.n_pipelined)
     if a.dist:
         dist.destroy_process_group()
 

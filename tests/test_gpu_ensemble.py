@@ -100,6 +100,22 @@ def test_prefetched_ensemble_walks_the_same_chain(tmp_path):
     assert list(grp["calls"]) == [96] * 12 and str(grp["backend"]) == "nccl"
     for key in ("states", "logll", "table", "swap_attempts", "swap_accepts", "n_acc"):
         np.testing.assert_array_equal(one[key], grp[key], err_msg=key)
+    # ... and with the decisions taken on the device, behind the launch on its stream (pt._DecidePipe: the host prepares
+    # the four proposal sets a launch's two decisions can ask for while it runs; no launch waits for the host): segments
+    # of three launches per group, two in flight
+    dd = _child(tmp_path, "dd", dist=1, parts=1, sort=1, rng_mode="counter", prefetch=1, iters=12, temper_freq=6,
+                groups=2, device_decisions=1, port=29621)
+    ref6 = _child(tmp_path, "ref6", dist=0, parts=1, sort=0, rng_mode="counter", prefetch=0, iters=12, temper_freq=6)
+    assert int(dd["n_pipelined"]) == 12 and list(dd["calls"]) == [] and str(dd["backend"]) == "nccl"
+    for key in ("states", "logll", "table", "swap_attempts", "swap_accepts", "n_acc"):
+        np.testing.assert_array_equal(ref6[key], dd[key], err_msg=key)
+    assert int(ref6["n_acc"]) > 0
+    # (device_decisions=1: the library's mtrpl_pt_select_dev / mtrpl_pt_decide_dev; 2: the same two steps as torch ops)
+    dd2 = _child(tmp_path, "dd2", dist=0, parts=1, sort=0, rng_mode="counter", prefetch=1, iters=12, temper_freq=6,
+                 groups=1, device_decisions=2)
+    assert int(dd2["n_pipelined"]) == 6 and list(dd2["calls"]) == []
+    for key in ("states", "logll", "table", "swap_attempts", "swap_accepts", "n_acc"):
+        np.testing.assert_array_equal(ref6[key], dd2[key], err_msg=key)
     # the fp64-block kernel walks the same chain: the same decisions, log-likelihoods to 1e-7
     f64 = _child(tmp_path, "f64", dist=0, parts=1, sort=1, rng_mode="counter", prefetch=1, iters=12, temper_freq=4,
                  kernel_variant=2)

@@ -62,6 +62,14 @@ def test_config4_512_chains_512_temperatures_on_one_gpu(tmp_path):
     for key in ("table0", "states", "logll", "table", "swap_attempts", "swap_accepts", "n_acc"):
         np.testing.assert_array_equal(a[key], b[key], err_msg=key)
     assert not np.array_equal(a["states"], a["states0"])
+    # (c) ... and with the decisions of a launch taken on the device (pt._DecidePipe, one iteration per launch: the host
+    # has both outcomes' proposals packed and on the device before the launch ends; 3072-solve launches in the engine's
+    # measured-cost order, split over two streams)
+    c = _child(tmp_path, "c512_dev", chains=512, dist=1, parts=2, sort=1, rng_mode="counter", prefetch=0, iters=10,
+               temper_freq=10, device_decisions=1, packed_order="solves", port=29633)
+    assert int(c["n_pipelined"]) == 10 and list(c["calls"]) == [] and int(c["n_parts"]) == 2 and bool(c["ordered"])
+    for key in ("table0", "states", "logll", "table", "swap_attempts", "swap_accepts", "n_acc"):
+        np.testing.assert_array_equal(a[key], c[key], err_msg=key)
 
 
 def test_ladder_of_512_temperatures_without_irf():

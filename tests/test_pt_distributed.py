@@ -91,15 +91,66 @@ def test_sharded_ensemble_equals_serial(world, n_chains):
     assert ref.swap_attempts.sum() == 3 * (n_chains - 1)
 
 
-def _run_counter(n_chains, iters, prefetch, rank=0, world=1, temper_freq=4, groups=1):
+class _PackedToy:
+    """The toy evaluator with the two extra entry points of an engine-backed one (pt_bench.setup): `pack_rows` lays M
+    'descriptors' per state row (here: the state's own bytes, and where a real one holds its output offset, the row's
+    position in its set) and `launch_packed` evaluates whatever descriptors the caller hands back."""
+    M = 2
+
+    def __init__(self, calls, own_order=False):
+        self.calls, self.own_order, self.order = calls, own_order, None
+        if own_order:
+            self.plan_packed = self._plan_packed
+        else:
+            self.row_cost = self._row_cost
+
+    def _plan_packed(self, states):
+        """An evaluator that issues its solves in an order of its own, fixed per stretch between two exchanges."""
+        n = states.shape[0] * self.M
+        self.prng = getattr(self, "prng", None) or np.random.default_rng(11)
+        self.order = self.prng.permutation(n)
+        return self.order // self.M
+
+    def __call__(self, block, temps):
+        self.calls.append(block.shape[0])
+        return _toy_evaluator(block, temps)
+
+    def pack_rows(self, states, sets=1):
+        st = np.ascontiguousarray(states, dtype=np.float64)
+        pos = np.tile(np.arange(st.shape[0] // sets, dtype=np.float64), sets)
+        d = np.repeat(np.concatenate([st, pos[:, None]], axis=1), self.M, axis=0)
+        if self.order is not None and self.order.shape[0] == d.shape[0] // sets:
+            d = d.reshape(sets, d.shape[0] // sets, -1)[:, self.order].reshape(d.shape[0], -1)
+        return np.ascontiguousarray(d).view(np.uint8).reshape(d.shape[0], -1)
+
+    def _row_cost(self, n_rows):  # "the last launch's cost per state row": makes the pipe re-order its chains every segment
+        self.rng = getattr(self, "rng", None) or np.random.default_rng(5)
+        return self.rng.random(n_rows)
+
+    def launch_packed(self, d, n_solves, temps):
+        x = d.view(torch.float64).view(n_solves, -1).numpy()
+        if self.order is not None and self.order.shape[0] == n_solves:
+            back = np.empty_like(x)
+            back[self.order] = x
+            x = back
+        np.testing.assert_array_equal(x[:, -1], np.repeat(np.arange(n_solves // self.M), self.M))  # every row in its place
+        self.calls.append(("packed", n_solves // self.M))
+        return _toy_evaluator(x[::self.M, :-1], temps)
+
+
+def _run_counter(n_chains, iters, prefetch, rank=0, world=1, temper_freq=4, groups=1, device_decisions=False,
+                 own_order=False):
     ens0 = W.pt_ensemble(n_chains)
     calls = []
 
     def ev(block, temps):
         calls.append(block.shape[0])
         return _toy_evaluator(block, temps)
-    e = pt.PTEnsemble(ens0["chain_states"], ens0["temperatures"], ev if groups == 1 else [ev] * groups, rank=rank,
-                      world=world, rng_mode="counter")
+    if device_decisions:
+        ev = [_PackedToy(calls, own_order) for _ in range(groups)]
+        ev = ev[0] if groups == 1 else ev
+    e = pt.PTEnsemble(ens0["chain_states"], ens0["temperatures"], ev if groups == 1 or device_decisions else [ev] * groups, rank=rank,
+                      world=world, rng_mode="counter", device_decisions=device_decisions)
     e.initialise()
     n_acc = e.advance(_proposer(), iters, temper_freq, prefetch=prefetch)
     return e, n_acc, calls
@@ -156,27 +207,54 @@ def test_chain_groups_walk_the_same_chain(groups, prefetch):
         pt.PTEnsemble(seq.states, seq.T, [_toy_evaluator] * 2)  # groups need counter-mode draws
 
 
-def _prefetch_worker(rank, world, port, n_chains, iters, groups, q):
+@pytest.mark.parametrize("groups,temper_freq,iters,prefetch,own_order",
+                         [(1, 4, 23, True, False), (1, 10, 31, True, False), (2, 10, 27, True, False), (3, 6, 19, True, True),
+                          (1, 3, 9, True, False), (1, 5, 17, False, False), (2, 4, 11, False, True), (1, 10, 20, False, True)])
+def test_device_side_decisions_walk_the_same_chain(groups, temper_freq, iters, prefetch, own_order):
+    """Prefetching with the decisions taken where the evaluator's results are (`_DecidePipe`: the host prepares the
+    four proposal sets the two decisions of the running launch can ask for, the device picks; two launches in flight,
+    segments of two to five launches, odd leftovers through the host path) == one iteration at a time, bit for bit."""
+    n_chains = 8
+    seq, acc_s, _ = _run_counter(n_chains, iters, False, temper_freq=temper_freq)
+    dev, acc_d, calls = _run_counter(n_chains, iters, prefetch, temper_freq=temper_freq, groups=groups, device_decisions=True,
+                                     own_order=own_order)
+    assert acc_d == acc_s and dev.it == iters and dev.git == [iters] * groups
+    np.testing.assert_array_equal(dev.states, seq.states)
+    np.testing.assert_array_equal(dev.logll, seq.logll)
+    np.testing.assert_array_equal(dev.table, seq.table)
+    np.testing.assert_array_equal(dev.acc_count, seq.acc_count)
+    np.testing.assert_array_equal(dev.swap_accepts, seq.swap_accepts)
+    packed = [c for c in calls if isinstance(c, tuple)]
+    depth = 2 if prefetch else 1
+    pairs = sum((min(iters, (k + 1) * temper_freq) - k * temper_freq) // depth for k in range(-(-iters // temper_freq)))
+    assert len(packed) == dev.n_pipelined == groups * pairs  # every whole launch of a segment went through the pipe
+    assert all(isinstance(c, tuple) or c in (n_chains, len(range(0, n_chains, groups)), len(range(groups - 1, n_chains, groups)))
+               for c in calls)  # ... and nothing else was a three-set launch
+
+
+def _prefetch_worker(rank, world, port, n_chains, iters, groups, q, device_decisions=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    e, n_acc, _ = _run_counter(n_chains, iters, True, rank, world, groups=groups)
+    e, n_acc, _ = _run_counter(n_chains, iters, True, rank, world, groups=groups, device_decisions=device_decisions)
     q.put((rank, e.states.copy(), e.logll.copy(), e.swap_accepts.copy(), n_acc, e.n_collectives, e.table.copy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_chains,groups", [(2, 8, 1), (3, 8, 1), (2, 8, 2), (3, 7, 2)])
-def test_prefetched_sharded_ensemble_equals_serial(world, n_chains, groups):
+@pytest.mark.parametrize("world,n_chains,groups,device_decisions", [(2, 8, 1, False), (3, 8, 1, False), (2, 8, 2, False),
+                                                                   (3, 7, 2, False), (2, 8, 2, True), (3, 7, 1, True)])
+def test_prefetched_sharded_ensemble_equals_serial(world, n_chains, groups, device_decisions):
     """Counter-mode draws: every rank proposes and decides for its own chain block only (three proposal sets per
     launch when prefetching) and the ranks exchange ONCE per replica exchange -- even and uneven chain blocks,
-    whole and in chain groups: the walk of the one-rank, one-iteration-at-a-time run, bit for bit."""
+    whole and in chain groups, decisions on the host or where the evaluator's results are: the walk of the one-rank,
+    one-iteration-at-a-time run, bit for bit."""
     iters = 11
     ref, acc_ref, _ = _run_counter(n_chains, iters, False)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_prefetch_worker, args=(r, world, port, n_chains, iters, groups, q))
+    procs = [ctx.Process(target=_prefetch_worker, args=(r, world, port, n_chains, iters, groups, q, device_decisions))
              for r in range(world)]
     for p in procs:
         p.start()
