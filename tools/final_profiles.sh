@@ -1,11 +1,14 @@
 #!/bin/bash
 # tools/final_profiles.sh TAG -- the bench / rocprofv3 / PMC set that profiles/ holds for a round (run on the GPU box via
 # gpurun AFTER the last code commit; everything lands in gpurun_out/, tools/collect_profiles.sh copies it to profiles/)
+# SECTIONS=wave,c5,pt,acc (default: all) limits the run to some of its parts.
 T=$1
+SEC=${SECTIONS:-wave,c5,pt,acc}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # bench.py sets this itself, but under rocprofv3 the runtime is up before Python starts
 export GPU_MAX_HW_QUEUES=8
 O=gpurun_out
+if [[ $SEC == *wave* ]]; then
 # ---- counters of the two builds of the wave kernel (each group in its own pass) ----
 tools/pmc.sh $T > $O/${T}_pmc.log 2>&1
 tools/pmc_mix.sh $T > $O/${T}_pmc_mix.log 2>&1
@@ -25,7 +28,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -- $BENCH > $
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${T}s1 -- $BENCH1 > $O/prof_${T}s1.log 2>&1
 cp $O/prof_$T/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_config2.csv
 cp $O/prof_${T}s1/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_config2_one_stream.csv
-# ---- config 5 (nx = 512): contract line, kernel statistics, counters of the team kernel ----
+fi
+if [[ $SEC == *c5* ]]; then
+# ---- config 5 (nx = 512): contract line, kernel statistics, counters of the SPIKE kernel ----
 timeout -k 10 300 python bench.py --workload config5 --steps 10 --warmup 2 > $O/${T}_bench_config5.json 2>> $O/${T}_bench.err
 C5="python3 bench.py --workload config5 --steps 4 --warmup 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${T}c5 -- $C5 > $O/prof_${T}c5.log 2>&1
@@ -35,21 +40,35 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc${T}c5_wr
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc${T}c5_sq -- $C5 > $O/pmc${T}c5_3.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/pmc${T}c5_sq2 -- $C5 > $O/pmc${T}c5_4.log 2>&1
 python tools/pmc_summary.py "solve_kernel_spike<" $O/hbm_traffic_${T}_spike4.json $O/pmc${T}c5_fetch $O/pmc${T}c5_write $O/pmc${T}c5_sq $O/pmc${T}c5_sq2 > $O/${T}_pmc_team.log 2>&1
+fi
+if [[ $SEC == *pt* ]]; then
 # ---- the parallel-tempering ensembles: contract lines, kernel statistics, counters of the likelihood kernel ----
 timeout -k 10 300 python bench.py --workload pt --chains 512 --steps 20 --warmup 10 > $O/${T}_bench_pt512_1gpu.json 2>> $O/${T}_bench.err
 timeout -k 10 300 python bench.py --workload pt --chains 64 --steps 40 --warmup 10 --no-cpu-baseline > $O/${T}_bench_pt64_1gpu.json 2>> $O/${T}_bench.err
-timeout -k 10 300 python bench.py --workload pt --chains 64 --steps 40 --warmup 10 --no-cpu-baseline --groups 1 --prefetch off > $O/${T}_bench_pt64_1gpu_plain.json 2>> $O/${T}_bench.err
+timeout -k 10 300 python bench.py --workload pt --chains 64 --steps 40 --warmup 10 --no-cpu-baseline --groups 1 --prefetch off --decide host > $O/${T}_bench_pt64_1gpu_plain.json 2>> $O/${T}_bench.err
+# ... and with the decisions on the host, as round 3 took them (two groups where prefetching, one otherwise)
+timeout -k 10 300 python bench.py --workload pt --chains 64 --steps 40 --warmup 10 --no-cpu-baseline --decide host > $O/${T}_bench_pt64_1gpu_host.json 2>> $O/${T}_bench.err
+timeout -k 10 300 python bench.py --workload pt --chains 512 --steps 20 --warmup 10 --no-cpu-baseline --decide host > $O/${T}_bench_pt512_1gpu_host.json 2>> $O/${T}_bench.err
 PT="python3 bench.py --workload pt --chains 512 --steps 5 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${T}pt -- $PT > $O/prof_${T}pt.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${T}pt64 -- python3 bench.py --workload pt --chains 64 --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_${T}pt64.log 2>&1
 cp $O/prof_${T}pt/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_pt512.csv
 cp $O/prof_${T}pt64/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_pt64.csv
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc${T}pt_sq -- $PT > $O/pmc${T}pt_3.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc${T}pt_fetch -- $PT > $O/pmc${T}pt_1.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc${T}pt_write -- $PT > $O/pmc${T}pt_2.log 2>&1
+# (the counters characterise the likelihood kernel by itself: one group, one 3072-trace launch of twelve-wave blocks at a
+# time; the one-wave blocks of the three-group ensemble produce the same table, tests/test_gpu_loglik_wave_blocks.py)
+PTL="python3 bench.py --workload pt --chains 512 --steps 5 --warmup 1 --no-cpu-baseline --groups 1 --decide host"
+export MTRPL_PARTS=1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc${T}pt_sq -- $PTL > $O/pmc${T}pt_3.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc${T}pt_fetch -- $PTL > $O/pmc${T}pt_1.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc${T}pt_write -- $PTL > $O/pmc${T}pt_2.log 2>&1
+unset MTRPL_PARTS
 python tools/pmc_summary.py "loglik_kernel<" $O/hbm_traffic_${T}_loglik.json $O/pmc${T}pt_fetch $O/pmc${T}pt_write $O/pmc${T}pt_sq > $O/${T}_pmc_loglik.log 2>&1
+fi
+if [[ $SEC == *c5* ]]; then
 # ---- config 5: fp32 / fp64 tolerance sweep on this build (the fp32 instantiation is the team kernel's) ----
 timeout -k 10 400 python tools/config5_sweep.py $O/${T}_config5_sweep.json > $O/${T}_config5_sweep.txt 2>&1
+fi
+if [[ $SEC == *acc* ]]; then
 # ---- the held-out converged set, where the steps of a solve go ----
 timeout -k 10 200 python tools/heldout_table.py > $O/${T}_heldout.txt 2>/dev/null
 MTRPL_LIB_PATH=$PWD/metrotrpl_amd/lib/libmetrotrpl_amd_trace.so timeout -k 10 200 python tools/startup_trace.py > $O/${T}_startup_trace.txt 2>/dev/null
@@ -58,6 +77,7 @@ timeout -k 10 200 python tools/tail_table.py --json $O/${T}_tail_decades.json --
 timeout -k 10 300 python tools/variant_agreement.py 8192 > $O/${T}_variant_agreement.txt 2>/dev/null
 timeout -k 10 100 python tools/solve_latency.py > $O/${T}_solve_latency.txt 2>/dev/null
 timeout -k 10 200 python tools/slow_solves.py > $O/${T}_slow_solves.txt 2>/dev/null
+fi
 cut -c1-260 $O/${T}_bench_*.json
 head -4 $O/${T}_kernel_stats_bench_config2.csv | cut -c1-200
 cat $O/${T}_solve_latency.txt

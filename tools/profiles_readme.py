@@ -76,11 +76,12 @@ b = load("bench_config5.json")
 if b:
     rows.append((f"`{T}_bench_config5.json`", f"`bench.py --workload config5`: **{b['value'] / 1e3:.1f} k solves/s** ({b['ms_per_step']:.2f} ms per 512-solve step, "
                                                f"{b['config']['streams']} streams), single stream {b['single_stream']['solves_per_sec'] / 1e3:.1f} k; kernel `{b['roofline']['kernel']}`"))
-for name in ("bench_pt512_1gpu.json", "bench_pt64_1gpu.json", "bench_pt64_1gpu_plain.json"):
+for name in ("bench_pt512_1gpu.json", "bench_pt64_1gpu.json", "bench_pt512_1gpu_host.json", "bench_pt64_1gpu_host.json",
+             "bench_pt64_1gpu_plain.json"):
     b = load(name)
     if b:
         rows.append((f"`{T}_{name}`", f"`bench.py --workload pt`: {b['config']['chains']} chains, {b['ms_per_step']:.2f} ms per iteration = {b['value'] / 1e3:.1f} k proposals/s "
-                                      f"(prefetch {b['config']['prefetch']}, {b['config']['chain_groups']} group(s))"))
+                                      f"(prefetch {b['config']['prefetch']}, {b['config']['chain_groups']} group(s), decisions on the {b['config'].get('decisions', 'host')})"))
 for name, what in (("tail_decades.txt", "per-decade accuracy table (config 2 / config-3 geometry)"), ("heldout.txt", "the held-out converged set, per decade"),
                    ("startup_trace.txt", "where the steps of a solve go along the time axis"), ("slow_solves.txt", "the slowest solves of the config-2 batch"),
                    ("variant_agreement.txt", "default kernel vs fp64-block kernel on 8192 draws"), ("solve_latency.txt", "latency of the drop-in `solve()`"),
