@@ -176,7 +176,7 @@ def _pt_leg(rank, world, local, dev, with_cpu, use_dist=False):
                 **({"cpu_baseline": ln["cpu_baseline"]} if "cpu_baseline" in ln else {})}
 
     # (with a process group the warm-up spans two replica exchanges: the first collective of each shape sets RCCL up)
-    for chains, steps, warm in ((64, 30, 10), (512, 10 if world == 1 else 30, 20 if use_dist else 10)):
+    for chains, steps, warm in ((64, 30, 10), (512, 20 if world == 1 else 30, 20 if use_dist else 10)):
         try:
             # the 64-chain ensemble is config 3, a ONE-GPU configuration: at N > 1 rank 0 runs it alone
             if chains == 64 and world > 1:

@@ -27,7 +27,11 @@ bench.py run in) or per iteration (draws in the reference's program order, "stre
     draw comes out of one generator in program order, so every rank has to replay every chain to stay
     in step with it, and the table is gathered at every iteration as before.
 
-Host logic only (numpy + torch.distributed); the evaluator is injected.
+  * with evaluators that can launch from descriptors kept on the device, the decisions of a launch are taken there
+    too (`_DecidePipe`): the host prepares the proposals of every outcome one launch ahead, and between two exchanges
+    no launch waits for it.
+
+Host logic only (numpy + torch tensors / torch.distributed); the evaluator -- and with it every kernel -- is injected.
 """
 import gc
 import time

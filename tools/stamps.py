@@ -21,10 +21,27 @@ from metrotrpl_amd import _lib as L, batch, workloads as W  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--variant", default="6,2")
 ap.add_argument("--batch", type=int, default=1024)
+ap.add_argument("--config5", action="store_true", help="the nx = 512 batch of bench.py --workload config5 (variant 0: SPIKE, 1: team)")
 a = ap.parse_args()
-c = W.config2(a.batch)
 ix, un = W.indexes(), W.units()
 ctx = L.default_context()
+if a.config5:
+    c = W.config5(max(1, a.batch // 4))
+    names = ["steps", "controller", "factorise", "rhs", "re-solve", "reduce+publish", "newton glue", "dense out"]
+    for variant in [int(v) for v in a.variant.split(",")]:
+        ctx.set_option("kernel_variant", variant)
+        for rep in range(2):
+            sig, status, st = batch.solve_batch(c["states"], ix, un, c["iniPar"], c["thickness"], c["nx"], c["tSteps"], hmax=c["hmax"],
+                                                meas=c["meas"], model=c["model"], ini_mode=c["ini_mode"], return_stats=True)
+        tot = st[:, 1:].sum(axis=1).astype(float)
+        print(f"config 5, variant {variant}, B {st.shape[0]}: mean steps {st[:, 0].mean():.0f}, mean total {tot.mean():.0f} kcycles (wave 0 of "
+              f"each solve), per step {1024 * tot.mean() / st[:, 0].mean():.0f} cycles")
+        for k in range(1, 8):
+            print(f"  {names[k]:15s}: {st[:, k].mean():9.0f} kcyc  {100 * st[:, k].sum() / tot.sum():5.1f}%   per step "
+                  f"{1024 * st[:, k].mean() / st[:, 0].mean():7.0f} cyc")
+    ctx.set_option("kernel_variant", 0)
+    sys.exit(0)
+c = W.config2(a.batch)
 names = ["steps", "controller", "factorise", "rhs", "re-solve", "reduce+publish", "newton glue", "dense out"]
 for variant in [int(v) for v in a.variant.split(",")]:
     ctx.set_option("kernel_variant", variant)
