@@ -287,6 +287,13 @@ class LikelihoodEngine:
         self._packed = (n, cuts, order)
         return (np.arange(n) if order is None else order) // self.M
 
+    def packable(self):
+        """Can launches run from descriptors picked on the device (`pack_rows` / `use_packed`)?  Only while the likelihood
+        descriptors and the initial-condition array do not depend on the state: no fitted scale factor, no density-mode
+        fittables."""
+        return not (self.fit["scale"].max() >= 0 or
+                    (self.ini_mode == "density" and max(self.fit["fluences"].max(), self.fit["absps"].max()) >= 0))
+
     def pack_rows(self, states, sets=1):
         """Solve descriptors of `states` [R, n_params] x M measurements as bytes [R * M, desc size]; `sets` > 1: the
         rows are that many alternative sets of R / sets state rows, each placed (output and initial-condition offsets)
@@ -294,7 +301,7 @@ class LikelihoodEngine:
         that hold several candidate sets on the device and pick rows there (pt.PTEnsemble's device-side decisions).
         Only for ensembles whose likelihood descriptors and initial-condition array do not depend on the state (no
         fitted scale factor, no density-mode fittables)."""
-        if self.fit["scale"].max() >= 0 or (self.ini_mode == "density" and max(self.fit["fluences"].max(), self.fit["absps"].max()) >= 0):
+        if not self.packable():
             raise NotImplementedError("packed launches need state-independent likelihood descriptors")
         keep = self.sort_by_cost, self.parts
         self.sort_by_cost, self.parts = False, 1

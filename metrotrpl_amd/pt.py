@@ -602,7 +602,7 @@ class PTEnsemble:
         for g in range(self.groups):
             ev = self.evaluators[g]
             n_launches = (seg_end - self.git[g]) // depth
-            if n_launches > 0 and hasattr(ev, "pack_rows") and hasattr(ev, "launch_packed"):
+            if n_launches > 0 and hasattr(ev, "pack_rows") and hasattr(ev, "launch_packed") and getattr(ev, "packable", True):
                 pipes.append(_DecidePipe(self, g, proposer, n_launches, depth))
         plans = [p.schedule() for p in pipes]
         for step in range(max((len(pl) for pl in plans), default=0)):
@@ -675,7 +675,8 @@ class _DecidePipe:
     evaluator issues them) and `launch_packed(descriptors on the device, n_solves, temperatures)` -> table [R / sets,
     nT]; optionally `plan_packed(states of one set)` -> the state row of every descriptor row (an evaluator that issues
     its solves in an order of its own; default: M consecutive rows per state row), `select` / `decide` (the two device
-    steps as one kernel each instead of torch operations) and `row_cost(R)` (cost per state row of the last launch)."""
+    steps as one kernel each instead of torch operations), `row_cost(R)` (cost per state row of the last launch) and
+    `packable` (False: this evaluator's descriptors cannot be chosen on the device -- its group walks the host path)."""
 
     def __init__(self, ens, g, proposer, n_launches, depth):
         import torch

@@ -83,7 +83,7 @@ def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=Tr
         def launch_packed(d_descs, n_solves, temps):
             eng.use_packed(d_descs, n_solves)
             return eng.launch(d_T, len(temps)).view(-1, eng.M, len(temps)).sum(dim=1)
-        evaluator.pack_rows, evaluator.launch_packed = eng.pack_rows, launch_packed
+        evaluator.pack_rows, evaluator.launch_packed, evaluator.packable = eng.pack_rows, launch_packed, eng.packable()
 
         # pt._DecidePipe: the two decisions of a launch and the pick of the next launch's descriptors, one kernel each
         def select(cand, n_cand, n_rows, chain_of_row, outcome, out):

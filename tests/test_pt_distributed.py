@@ -232,6 +232,23 @@ def test_device_side_decisions_walk_the_same_chain(groups, temper_freq, iters, p
                for c in calls)  # ... and nothing else was a three-set launch
 
 
+def test_an_evaluator_that_cannot_pack_walks_the_host_path():
+    """`packable = False` (a LikelihoodEngine with a fitted scale factor): device_decisions is asked for, the group's
+    launches go through `_begin` / `_end` all the same, and the chain is the same."""
+    n_chains, iters = 8, 12
+    seq, acc_s, _ = _run_counter(n_chains, iters, False)
+    ens0 = W.pt_ensemble(n_chains)
+    calls = []
+    ev = _PackedToy(calls)
+    ev.packable = False
+    e = pt.PTEnsemble(ens0["chain_states"], ens0["temperatures"], ev, rng_mode="counter", device_decisions=True)
+    e.initialise()
+    acc = e.advance(_proposer(), iters, 4, prefetch=True)
+    assert acc == acc_s and e.n_pipelined == 0 and not any(isinstance(c, tuple) for c in calls)
+    np.testing.assert_array_equal(e.states, seq.states)
+    np.testing.assert_array_equal(e.table, seq.table)
+
+
 def _prefetch_worker(rank, world, port, n_chains, iters, groups, q, device_decisions=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
