@@ -598,17 +598,34 @@ class PTEnsemble:
         """Every whole launch of `depth` iterations up to `seg_end`, for the groups whose evaluator can launch from
         descriptors kept on the device, with the decisions taken there (`_DecidePipe`); the groups' host work is
         interleaved."""
-        pipes = []
+        todo = []
         for g in range(self.groups):
             ev = self.evaluators[g]
             n_launches = (seg_end - self.git[g]) // depth
             if n_launches > 0 and hasattr(ev, "pack_rows") and hasattr(ev, "launch_packed") and getattr(ev, "packable", True):
-                pipes.append(_DecidePipe(self, g, proposer, n_launches, depth))
-        plans = [p.schedule() for p in pipes]
-        for step in range(max((len(pl) for pl in plans), default=0)):
-            for p, pl in zip(pipes, plans):
-                if step < len(pl):
-                    getattr(p, pl[step][0])(pl[step][1])
+                todo.append((g, n_launches))
+        # The first launch of a stretch is what the device waits for (it idles from the last decision before the exchange
+        # until then): its proposals are made for all the groups at once, and a group's pipe is built right before its
+        # first launch goes out, not before everybody's.
+        first = None
+        if len(todo) > 1 and len({self.git[g] for g, _ in todo}) == 1:
+            allsel = np.concatenate([self.own[g] for g, _ in todo])
+            if allsel.shape[0]:
+                it = self.git[todo[0][0]]
+                xs, Ts = self.states[allsel], self.T[allsel]
+                rows = lambda i: _Rows(self.draws(i, PROPOSE), self.n, allsel)  # noqa: E731
+                ys = [proposer(xs, Ts, rows(it + 1))]
+                if depth == 2:
+                    ys += [proposer(xs, Ts, rows(it + 2)), proposer(ys[0], Ts, rows(it + 2))]
+                first = (dict(zip(allsel.tolist(), range(allsel.shape[0]))), ys)
+        pipes, plans = [], []
+        for step in range(2 * max((n for _, n in todo), default=0) + 2):
+            for k, (g, n_launches) in enumerate(todo):
+                if step == 0:
+                    pipes.append(_DecidePipe(self, g, proposer, n_launches, depth, first))
+                    plans.append(pipes[-1].schedule())
+                if step < len(plans[k]):
+                    getattr(pipes[k], plans[k][step][0])(plans[k][step][1])
 
     def advance(self, proposer, n_iters, temper_freq, prefetch=False):
         """`n_iters` iterations with a replica exchange after every `temper_freq`-th (metropolis.py:129).
@@ -678,9 +695,10 @@ class _DecidePipe:
     steps as one kernel each instead of torch operations), `row_cost(R)` (cost per state row of the last launch) and
     `packable` (False: this evaluator's descriptors cannot be chosen on the device -- its group walks the host path)."""
 
-    def __init__(self, ens, g, proposer, n_launches, depth):
+    def __init__(self, ens, g, proposer, n_launches, depth, first=None):
         import torch
         self.torch, self.ens, self.g, self.proposer, self.L, self.depth = torch, ens, g, proposer, n_launches, depth
+        self.first = first  # (chain -> row, [y1, y2r, y2a] of all the groups' chains): the first launch's proposals, made already
         self.G = 3 if depth == 2 else 1  # proposals per chain and launch
         self.ev = ens.evaluators[g]
         self.stream = ens.streams[g]
@@ -758,12 +776,18 @@ class _DecidePipe:
         S = cands.reshape(nc * c, -1)
         Tt = np.tile(self.Ts, nc)
         rows = lambda i: _TiledRows(ens.draws(i, PROPOSE), ens.n, self.sel, nc)  # noqa: E731
-        ys = [self.proposer(S, Tt, rows(it + 1))]
         u = np.zeros((2, c))
         u[0] = ens.draws(it + 1, ACCEPT).random(ens.n)[self.sel]
         if G == 3:
-            ys += [self.proposer(S, Tt, rows(it + 2)), self.proposer(ys[0], Tt, rows(it + 2))]
             u[1] = ens.draws(it + 2, ACCEPT).random(ens.n)[self.sel]
+        if j == 0 and self.first is not None:
+            pos = np.array([self.first[0][ch] for ch in self.sel.tolist()])
+            ys = [y[pos] for y in self.first[1]]
+            self.first = None
+        else:
+            ys = [self.proposer(S, Tt, rows(it + 1))]
+            if G == 3:
+                ys += [self.proposer(S, Tt, rows(it + 2)), self.proposer(ys[0], Tt, rows(it + 2))]
         props = np.stack([y.reshape(nc, c, -1) for y in ys], axis=1)  # [nc, G, c, n_params]
         ens._tick("propose", t0)
         t0 = time.perf_counter()

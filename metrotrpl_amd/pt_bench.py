@@ -102,10 +102,12 @@ def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=Tr
             return eng.d_stats[:8 * n_rows * eng.M].view(n_rows, eng.M, 8)[:, :, 0].max(dim=1).values.cpu().numpy()
         # the order of a packed launch's solves: big launches solve by solve (the engine's measured-cost order and
         # stream split, fixed per stretch between two exchanges), small ones chain by chain (pt._DecidePipe)
+        # (chain by chain -- evaluator.row_cost = row_cost -- measured nothing on the three-group 64-chain ensemble:
+        # 2.37 ms per iteration with it, without it and solve by solve; it costs a blocking read per group and stretch)
         if os.environ.get("MTRPL_PT_NO_ORDER") != "1":
             if packed_order == "solves":
                 evaluator.plan_packed = eng.plan_packed
-            else:
+            elif os.environ.get("MTRPL_PT_CHAIN_ORDER") == "1":
                 evaluator.row_cost = row_cost
         return eng, evaluator
     made = [make(g) for g in range(max(1, groups))]
@@ -175,7 +177,8 @@ def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups
     small = prefetch and groups > 1
     S = setup(n_chains, dev, local, sort_by_cost=os.environ.get("MTRPL_NO_SORT") != "1",
               parts=int(os.environ.get("MTRPL_PARTS", "2" if groups == 1 else "1")), groups=groups,
-              packed_order="chains" if small else "solves")
+              packed_order=os.environ.get("MTRPL_PT_ORDER", "chains" if small else "solves"),
+              sort_min=int(os.environ.get("MTRPL_PT_SORT_MIN", "1024")))
     eng, ens0, T, proposer = S["eng"], S["ens0"], S["T"], S["proposer"]
     # history-free draws (pt.PTEnsemble "counter" mode): the chain walked does not depend on N, on prefetching
     # or on the chain groups
