@@ -302,8 +302,10 @@ class PTEnsemble:
     In counter mode `states`, `logll` and `table` are complete on every rank after `initialise`, after a
     replica exchange and after `advance` / `sync`; in between a rank keeps only its own rows current."""
 
+    _frozen = False  # gc.freeze() has been called by an ensemble of this process (advance)
+
     def __init__(self, states, temperatures, evaluator, rank=0, world=1, seed=235817049752375780, group=None,
-                 rng_mode="stream", streams=None, device_decisions=False):
+                 rng_mode="stream", streams=None, device_decisions=False, gc_freeze=True):
         if rng_mode not in ("stream", "counter"):
             raise ValueError("rng_mode must be 'stream' or 'counter'")
         self.states = np.array(states, dtype=np.float64)
@@ -341,6 +343,7 @@ class PTEnsemble:
         self.prof = None  # a dict: host seconds per phase of the loop (tools/pt_host_phases.py)
         self.chain_cost = np.zeros(self.n)  # what the evaluator said a chain's last evaluation cost (own rows; 0 = unknown)
         self.device_decisions = bool(device_decisions)
+        self.gc_freeze = bool(gc_freeze)
         self.n_pipelined = 0  # launches decided on the device so far
 
     def _tick(self, key, t0):
@@ -634,7 +637,15 @@ class PTEnsemble:
         -> accepted moves of the whole ensemble (counter mode: `states`, `logll`, `table` are complete again on
         return)."""
         # (no cyclic garbage collection between two launches: a full collection walks every object of the process --
-        # tens of milliseconds with torch loaded, a dozen launches' worth -- and this loop creates no cycles)
+        # tens of milliseconds with torch loaded, a dozen launches' worth -- and this loop creates no cycles.  Switching
+        # it off only postpones that collection to the moment it is switched on again, so before the first stretch
+        # everything that exists -- the imported modules, the engines: nothing of it is garbage -- is moved out of the
+        # collector's sight once, gc.freeze(); later full collections look at what was created since and take a
+        # millisecond.  `gc_freeze=False` leaves the collector alone.)
+        if self.gc_freeze and not PTEnsemble._frozen:
+            gc.collect()
+            gc.freeze()
+            PTEnsemble._frozen = True
         gc_was = gc.isenabled()
         gc.disable()
         try:

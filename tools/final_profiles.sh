@@ -54,6 +54,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${T}pt -- $PT > 
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${T}pt64 -- python3 bench.py --workload pt --chains 64 --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_${T}pt64.log 2>&1
 cp $O/prof_${T}pt/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_pt512.csv
 cp $O/prof_${T}pt64/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_pt64.csv
+# ... the launch cycles of the groups from longer traces (per hardware queue: solve / likelihood kernel times, the gap from
+# one solve to the next; per stretch between two exchanges: when each queue starts and ends), and the host's share
+rocprofv3 --kernel-trace --output-format csv -d $O/prof_${T}pt64l -- python3 bench.py --workload pt --chains 64 --steps 60 --warmup 10 --no-cpu-baseline > $O/prof_${T}pt64l.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/prof_${T}pt512l -- python3 bench.py --workload pt --chains 512 --steps 30 --warmup 10 --no-cpu-baseline > $O/prof_${T}pt512l.log 2>&1
+for n in 64 512; do
+  { python tools/pt_timeline.py $O/prof_${T}pt${n}l/*/*_kernel_trace.csv; python tools/pt_segments.py $O/prof_${T}pt${n}l/*/*_kernel_trace.csv; } > $O/${T}_pt${n}_timeline.txt 2>/dev/null
+done
+{ timeout -k 10 100 python tools/pt_host_phases.py 64 100; PT_DECIDE=host PT_GROUPS=2 timeout -k 10 100 python tools/pt_host_phases.py 64 100; } > $O/${T}_pt64_host_phases.txt 2>/dev/null
 # (the counters characterise the likelihood kernel by itself: one group, one 3072-trace launch of twelve-wave blocks at a
 # time; the one-wave blocks of the three-group ensemble produce the same table, tests/test_gpu_loglik_wave_blocks.py)
 PTL="python3 bench.py --workload pt --chains 512 --steps 5 --warmup 1 --no-cpu-baseline --groups 1 --decide host"

@@ -85,7 +85,10 @@ for name in ("bench_pt512_1gpu.json", "bench_pt64_1gpu.json", "bench_pt512_1gpu_
 for name, what in (("tail_decades.txt", "per-decade accuracy table (config 2 / config-3 geometry)"), ("heldout.txt", "the held-out converged set, per decade"),
                    ("startup_trace.txt", "where the steps of a solve go along the time axis"), ("slow_solves.txt", "the slowest solves of the config-2 batch"),
                    ("variant_agreement.txt", "default kernel vs fp64-block kernel on 8192 draws"), ("solve_latency.txt", "latency of the drop-in `solve()`"),
-                   ("config5_sweep.txt", "config 5: fp32 / fp64 tolerance sweep on this build"), ("issue_cost.txt", "issue cost of the instruction classes")):
+                   ("config5_sweep.txt", "config 5: fp32 / fp64 tolerance sweep on this build"), ("issue_cost.txt", "issue cost of the instruction classes"),
+                   ("pt64_timeline.txt", "64-chain PT from a `rocprofv3 --kernel-trace`: per hardware queue (= chain group) the solve / likelihood kernel times and the gap from one solve to the next; per stretch between two exchanges when each group starts and ends"),
+                   ("pt512_timeline.txt", "the same for the 512-chain ensemble"),
+                   ("pt64_host_phases.txt", "64-chain PT: host milliseconds per launch cycle and phase, decisions on the device (three groups) and on the host (two)")):
     if os.path.exists(os.path.join(P, f"{T}_{name}")):
         rows.append((f"`{T}_{name}`", what))
 

@@ -6,8 +6,9 @@ import sys
 import time
 from types import SimpleNamespace
 
-import numpy as np
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # as bench.py does: every chain group's stream on a hardware queue of its own
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,11 +17,11 @@ from metrotrpl_amd import pt, pt_bench  # noqa: E402
 n_chains = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 dev = torch.device("cuda", 0)
-groups = int(os.environ.get("GROUPS", "2"))
+groups = int(os.environ.get("PT_GROUPS", "3"))  # (not GROUPS: bash owns that name)
 small = groups > 1
 S = pt_bench.setup(n_chains, dev, 0, parts=1, groups=groups)
 ens = pt.PTEnsemble(S["ens0"]["chain_states"], S["T"], S["evaluators"] if groups > 1 else S["evaluator"], rng_mode="counter",
-                    streams=S["streams"], group=pt.LOCAL_ONLY, device_decisions=os.environ.get("DECIDE", "device") == "device")
+                    streams=S["streams"], group=pt.LOCAL_ONLY, device_decisions=os.environ.get("PT_DECIDE", "device") == "device")
 ens.initialise()
 ens.advance(S["proposer"], 20, 10, True)
 torch.cuda.synchronize()
@@ -51,6 +52,16 @@ S["proposer"].__class__.__call__ = counting
 ens.prof = {}
 for e in S["engines"]:
     e.prof = {}
+marks = []
+_ex = ens._exchange
+
+
+def marked(it):
+    marks.append(time.perf_counter())
+    _ex(it)
+
+
+ens._exchange = marked
 t0 = time.perf_counter()
 ens.advance(S["proposer"], iters, 10, True)
 torch.cuda.synchronize()
@@ -65,3 +76,5 @@ up = sum(e.prof.get("upload", 0) for e in S["engines"]) / cycles * 1e3
 la = sum(e.prof.get("launch", 0) for e in S["engines"]) / cycles * 1e3
 print(f"  of enqueue: pack + upload {up:.3f}, kernel launches {la:.3f}")
 print("redraw rounds per proposer call: mean", np.mean(rounds), "max", np.max(rounds), "calls", len(rounds), "calls with > 10 rounds", int(np.sum(np.array(rounds) > 10)))
+print("ms per stretch of ten iterations:", " ".join(f"{(b - a) * 1e3:.1f}" for a, b in zip([t0] + marks[:-1], marks)))
+print("sum of the phases above", round(sum(v for k, v in ens.prof.items() if not k.endswith('.max')) * 1e3, 1), "ms of", round(dt * 1e3, 1))
