@@ -684,9 +684,10 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
             }
             // one thread per temperature, its samples in order; a thread that owns several temperatures (a small block
             // under a long ladder) walks the samples once for all of them: independent chains for the reciprocals
-            constexpr int KT = (BLK >= 256) ? 1 : 8;
+            constexpr int KT = (BLK >= 512) ? 1 : ((BLK >= 256) ? 2 : ((BLK >= 128) ? 4 : 8));
             for (int j0 = tid; j0 < nT; j0 += BLK * KT) {
                 double sT[KT], tot[KT];
+                const int kmax = (nT - (j0 - tid) + BLK - 1) / BLK;  // temperatures left for the block's first thread: uniform
 #pragma unroll
                 for (int k = 0; k < KT; ++k) {
                     const int j = j0 + k * BLK;
@@ -696,7 +697,8 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
                 for (int i = 0; i < n_c; ++i) {
                     const double e = e2[i], u = u2[i];
 #pragma unroll
-                    for (int k = 0; k < KT; ++k) tot[k] += e * frcp1(sT[k] + u);
+                    for (int k = 0; k < KT; ++k)
+                        if (k < kmax) tot[k] += e * frcp1(sT[k] + u);
                 }
 #pragma unroll
                 for (int k = 0; k < KT; ++k) {
@@ -732,8 +734,8 @@ __device__ inline void loglik_trace(const mtrpl_like_desc ds, int64_t sidx, cons
 // run to tens of thousands of samples, and the reference has no limit (trial_move_evaluation.py:96-158)
 // -- keep only the IRF work space in LDS and put the per-sample arrays in a per-block slab of global
 // memory (GWORK = true; L2-resident, written and read by this block only), blocks striding over the
-// traces.  BLK = 64 (GWORK only, nT >= 32 -- there no sum depends on the block size: the same numbers bit for bit):
-// one wave per block and 9 KB of LDS, a block that fits wherever ONE solve wave has left -- for likelihood launches
+// traces.  BLK = 64 / 128 / 256 (GWORK only, nT >= 32 -- there no sum depends on the block size: the same numbers bit for
+// bit): one, two or four waves per block and 9 KB of LDS, a block that fits wherever one (two, four) solve waves have left -- for likelihood launches
 // that share the device with another stream's queued solves, where a twelve-wave block with 57 KB of LDS waits
 // until that queue has drained.
 template <bool GWORK, int BLK>

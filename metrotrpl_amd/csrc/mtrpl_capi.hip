@@ -54,7 +54,7 @@ struct mtrpl_ctx {
     int precision = 64;      // 64: fp64 (the product); 32: the fp32 build of the team kernel (precision sweep only)
     size_t like_lds_attr = 64 * 1024;  // dynamic-LDS limit the likelihood kernel has been raised to
     unsigned long long call_id = 0;
-    int loglik_wave_blocks = 0;  // 1: likelihood launches with nT >= 32 run one wave per block (see include/metrotrpl_amd.h)
+    int loglik_wave_blocks = 0;  // 1 / 2 / 4: likelihood launches with nT >= 32 run that many waves per block (see include/metrotrpl_amd.h)
     int two_per_simd_min_batch = 1025;  // kernel_variant 0: launches of at least this many std / nx <= 128 solves use
                                         // the two-solves-per-SIMD build of the wave kernel (more than one solve per
                                         // SIMD anyway), smaller ones the one-per-SIMD build: same results
@@ -524,7 +524,9 @@ int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value)
     } else if (k == "two_per_simd_min_batch") {
         ctx->two_per_simd_min_batch = (int)value;
     } else if (k == "loglik_wave_blocks") {
-        ctx->loglik_wave_blocks = value != 0;
+        if (value != 0 && value != 1 && value != 2 && value != 4)
+            return bad(ctx, MTRPL_ERR_BAD_ARG, "loglik_wave_blocks must be 0 (twelve waves per trace), 1, 2 or 4 (waves per block)");
+        ctx->loglik_wave_blocks = (int)value;
     } else if (k == "precision") {
         if (value != 32 && value != 64) return bad(ctx, MTRPL_ERR_BAD_ARG, "precision must be 32 or 64");
         ctx->precision = (int)value;

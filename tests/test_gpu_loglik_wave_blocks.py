@@ -29,11 +29,14 @@ def test_wave_blocks_give_the_same_table(n_T, irf):
     states = W.pt_ensemble(64)["chain_states"][::5]  # 13 states across the prior box
     T = W.ladder(n_T)
     ref = eng.eval(states, T)
-    ctx.set_option("loglik_wave_blocks", 1)
-    assert ctx.get_option("loglik_wave_blocks") == 1
-    got = eng.eval(states, T)
-    ctx.set_option("loglik_wave_blocks", 0)
     assert ref.shape == (13, 6, n_T) and np.all(np.isfinite(ref))
-    np.testing.assert_array_equal(got, ref)
+    for waves in (1, 2, 4):
+        ctx.set_option("loglik_wave_blocks", waves)
+        assert ctx.get_option("loglik_wave_blocks") == waves
+        got = eng.eval(states, T)
+        np.testing.assert_array_equal(got, ref, err_msg=f"{waves} wave(s) per block")
+    ctx.set_option("loglik_wave_blocks", 0)
+    with pytest.raises(ValueError):
+        ctx.set_option("loglik_wave_blocks", 3)
     assert np.all(np.diff(ref, axis=2) > 0)  # ll(T) rises with T
     torch.cuda.synchronize()
