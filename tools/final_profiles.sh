@@ -75,6 +75,8 @@ fi
 if [[ $SEC == *c5* ]]; then
 # ---- config 5: fp32 / fp64 tolerance sweep on this build (the fp32 instantiation is the team kernel's) ----
 timeout -k 10 400 python tools/config5_sweep.py $O/${T}_config5_sweep.json > $O/${T}_config5_sweep.txt 2>&1
+# ---- where the cycles of a step go (-DMTRPL_STAMPS diagnostic build: s_memtime per phase), SPIKE at nx = 512 and the one-wave kernel
+{ timeout -k 10 300 python tools/stamps.py --config5 --variant 0 --batch 512; timeout -k 10 300 python tools/stamps.py --variant 6,3 --batch 1024; } 2>/dev/null | grep -v amdgpu.ids > $O/${T}_step_phases.txt
 fi
 if [[ $SEC == *acc* ]]; then
 # ---- the held-out converged set, where the steps of a solve go ----

@@ -86,6 +86,7 @@ for name, what in (("tail_decades.txt", "per-decade accuracy table (config 2 / c
                    ("startup_trace.txt", "where the steps of a solve go along the time axis"), ("slow_solves.txt", "the slowest solves of the config-2 batch"),
                    ("variant_agreement.txt", "default kernel vs fp64-block kernel on 8192 draws"), ("solve_latency.txt", "latency of the drop-in `solve()`"),
                    ("config5_sweep.txt", "config 5: fp32 / fp64 tolerance sweep on this build"), ("issue_cost.txt", "issue cost of the instruction classes"),
+                   ("step_phases.txt", "cycles per integrator step and phase (`-DMTRPL_STAMPS` diagnostic build): SPIKE at nx = 512, the one-wave kernel one and two per SIMD"),
                    ("pt64_timeline.txt", "64-chain PT from a `rocprofv3 --kernel-trace`: per hardware queue (= chain group) the solve / likelihood kernel times and the gap from one solve to the next; per stretch between two exchanges when each group starts and ends"),
                    ("pt512_timeline.txt", "the same for the 512-chain ensemble"),
                    ("pt64_host_phases.txt", "64-chain PT: host milliseconds per launch cycle and phase, decisions on the device (three groups) and on the host (two)")):
