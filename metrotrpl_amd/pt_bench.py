@@ -128,6 +128,11 @@ def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=Tr
 
 
 def run(a, rank, world, local, dev, cpu_baseline_fn=None):
+    """One `bench.py --workload pt` line (also the `pt` legs of the default line).  Experiment switches, all off by default
+    (environment): MTRPL_NO_SORT=1 / MTRPL_PARTS=n (the engine's measured-cost order / stream split), MTRPL_PT_NO_ORDER=1
+    (packed launches as given), MTRPL_PT_CHAIN_ORDER=1 (small packed launches chain by chain, most expensive first),
+    MTRPL_LL_WAVE=0|1|2|4 (waves per likelihood block where several throughput-bound groups share the device; 0 = twelve),
+    MTRPL_PT_PROF=1 (host milliseconds per phase into config.host_ms)."""
     import torch
     n_chains = a.chains
     # Prefetching (pt.PTEnsemble.iterate2): when this rank's block leaves most SIMDs idle -- one solve occupies one
@@ -177,8 +182,7 @@ def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups
     small = prefetch and groups > 1
     S = setup(n_chains, dev, local, sort_by_cost=os.environ.get("MTRPL_NO_SORT") != "1",
               parts=int(os.environ.get("MTRPL_PARTS", "2" if groups == 1 else "1")), groups=groups,
-              packed_order=os.environ.get("MTRPL_PT_ORDER", "chains" if small else "solves"),
-              sort_min=int(os.environ.get("MTRPL_PT_SORT_MIN", "1024")))
+              packed_order="chains" if small else "solves")
     eng, ens0, T, proposer = S["eng"], S["ens0"], S["T"], S["proposer"]
     # history-free draws (pt.PTEnsemble "counter" mode): the chain walked does not depend on N, on prefetching
     # or on the chain groups
