@@ -189,7 +189,7 @@ def _pt_leg(rank, world, local, dev, with_cpu, use_dist=False):
                 # at the barrier below), so that the line carries its own N = 1 figure
                 out["512"]["scaling"] = "strong"
                 if rank == 0:
-                    one = leg(512, 10, 10, 0, 1, False, False)
+                    one = leg(512, 20, 10, 0, 1, False, False)
                     out["512"]["one_gpu_same_build"] = one
                     out["512"]["speedup_vs_one_gpu"] = one["ms_per_iteration"] / out["512"]["ms_per_iteration"]
         except Exception as e:  # the solves/s contract line must not depend on this leg
