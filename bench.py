@@ -35,7 +35,6 @@ is gone.)  Measured in the same run and reported beside it:
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys

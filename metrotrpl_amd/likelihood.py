@@ -10,7 +10,6 @@ leave HBM; only the [C, M, nT] log-likelihood table is produced.
 
 torch is used for device buffers only (allocation, H2D/D2H, the current stream).
 """
-import ctypes as C
 
 import numpy as np
 

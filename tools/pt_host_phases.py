@@ -4,7 +4,6 @@ of pt.PTEnsemble (propose / enqueue = pack + upload + kernel launches / wait for
 import os
 import sys
 import time
-from types import SimpleNamespace
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # as bench.py does: every chain group's stream on a hardware queue of its own
 import numpy as np  # noqa: E402
