@@ -34,6 +34,7 @@ bench.py run in) or per iteration (draws in the reference's program order, "stre
 Host logic only (numpy + torch tensors / torch.distributed); the evaluator -- and with it every kernel -- is injected.
 """
 import gc
+import math
 import time
 
 import numpy as np
@@ -135,16 +136,24 @@ def metropolis_accept(logll_cur, logll_new, rng, rows=None):
         return u < np.exp(lr)
 
 
-def replica_exchange(table, rng):
+def replica_exchange(table, rng, batched_draws=False):
     """metropolis.py:129-135 + :66-90 on the gathered table.
 
     table[c, k] = log-likelihood of the state currently held by chain c at ladder
     temperature k.  Returns (owner, attempts, accepts): owner[k] = index of the
-    state that sits at temperature slot k afterwards."""
+    state that sits at temperature slot k afterwards.
+    batched_draws: the n - 1 pair indices and the n - 1 accept rolls as two draws instead of alternating one by one
+    as the reference's loop does -- another, equally random sequence of attempts, three times cheaper to produce (the
+    generator calls are most of this loop); for the history-free "counter" draws, which are nobody's stream to follow."""
     n = table.shape[0]
     owner = list(range(n))
     attempts, accepts = [0] * n, [0] * n
     item, integers, random, exp = table.item, rng.integers, rng.random, np.exp
+    if batched_draws and n > 1:
+        pairs = iter(rng.integers(0, n - 1, size=n - 1).tolist())
+        rolls = iter(rng.random(n - 1).tolist())
+        integers, random = (lambda lo, hi: next(pairs)), (lambda: next(rolls))
+        exp = lambda x: math.exp(x) if x < 700.0 else (math.inf if x >= 700.0 else x)  # noqa: E731 (a NaN ratio stays NaN: rejected)
     with np.errstate(over="ignore", invalid="ignore"):
         for _ in range(n - 1):
             i = int(integers(0, n - 1))
@@ -556,7 +565,7 @@ class PTEnsemble:
 
     def _exchange_(self, it):
         self.sync()
-        owner, att, accs = replica_exchange(self.table, self.draws(it, SWAP))
+        owner, att, accs = replica_exchange(self.table, self.draws(it, SWAP), batched_draws=self.rng_mode == "counter")
         self.states = self.states[owner]
         self.table = self.table[owner]
         self.chain_cost = self.chain_cost[owner]

@@ -327,6 +327,30 @@ def test_replica_exchange_matches_reference_rule():
     assert att.sum() == n - 1 and acc.sum() <= att.sum()
 
 
+def test_replica_exchange_with_batched_draws_applies_the_same_rule():
+    """The counter-mode form (pair indices and accept rolls drawn as two arrays, math.exp) takes, attempt by attempt, the
+    decision np.exp takes on the same pair and roll -- NaN (inf - inf), +-inf and overflowing ratios included."""
+    for trial in range(60):
+        rng = np.random.default_rng(trial)
+        n = int(rng.integers(2, 40))
+        table = -rng.random((n, n)) * 10.0 ** rng.integers(0, 4)
+        for _ in range(3):
+            table[rng.integers(0, n), rng.integers(0, n)] = rng.choice([np.nan, -np.inf, np.inf, 1e308, -1e308])
+        owner, att, acc = pt.replica_exchange(table, np.random.default_rng(7), batched_draws=True)
+        g = np.random.default_rng(7)
+        pairs, rolls = g.integers(0, n - 1, size=n - 1), g.random(n - 1)
+        who, n_acc = list(range(n)), [0] * n
+        with np.errstate(all="ignore"):
+            for i, u in zip(pairs, rolls):
+                a, b = who[i], who[i + 1]
+                if u < np.exp(-(table[a, i] + table[b, i + 1] - table[b, i] - table[a, i + 1])):
+                    who[i], who[i + 1] = b, a
+                    n_acc[i] += 1
+        assert who == owner.tolist() and n_acc == acc.tolist() and att.sum() == n - 1
+    o1, _, _ = pt.replica_exchange(np.zeros((1, 1)), np.random.default_rng(0), batched_draws=True)
+    assert o1.tolist() == [0]
+
+
 def test_propose_respects_box_and_physics():
     names, ix = W.PARAM_NAMES, W.indexes()
     active = [n in W.PRIOR_BOX for n in names]
