@@ -43,12 +43,12 @@ python tools/pmc_summary.py "solve_kernel_spike<" $O/hbm_traffic_${T}_spike4.jso
 fi
 if [[ $SEC == *pt* ]]; then
 # ---- the parallel-tempering ensembles: contract lines, kernel statistics, counters of the likelihood kernel ----
-timeout -k 10 300 python bench.py --workload pt --chains 512 --steps 20 --warmup 10 > $O/${T}_bench_pt512_1gpu.json 2>> $O/${T}_bench.err
+timeout -k 10 300 python bench.py --workload pt --chains 512 --steps 40 --warmup 10 > $O/${T}_bench_pt512_1gpu.json 2>> $O/${T}_bench.err
 timeout -k 10 300 python bench.py --workload pt --chains 64 --steps 40 --warmup 10 --no-cpu-baseline > $O/${T}_bench_pt64_1gpu.json 2>> $O/${T}_bench.err
 timeout -k 10 300 python bench.py --workload pt --chains 64 --steps 40 --warmup 10 --no-cpu-baseline --groups 1 --prefetch off --decide host > $O/${T}_bench_pt64_1gpu_plain.json 2>> $O/${T}_bench.err
 # ... and with the decisions on the host, as round 3 took them (two groups where prefetching, one otherwise)
 timeout -k 10 300 python bench.py --workload pt --chains 64 --steps 40 --warmup 10 --no-cpu-baseline --decide host > $O/${T}_bench_pt64_1gpu_host.json 2>> $O/${T}_bench.err
-timeout -k 10 300 python bench.py --workload pt --chains 512 --steps 20 --warmup 10 --no-cpu-baseline --decide host > $O/${T}_bench_pt512_1gpu_host.json 2>> $O/${T}_bench.err
+timeout -k 10 300 python bench.py --workload pt --chains 512 --steps 40 --warmup 10 --no-cpu-baseline --decide host > $O/${T}_bench_pt512_1gpu_host.json 2>> $O/${T}_bench.err
 PT="python3 bench.py --workload pt --chains 512 --steps 5 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${T}pt -- $PT > $O/prof_${T}pt.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${T}pt64 -- python3 bench.py --workload pt --chains 64 --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_${T}pt64.log 2>&1
