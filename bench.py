@@ -14,7 +14,7 @@ synthetic batch per GPU, nx=128, thickness 2000 nm, 1001 output times over
 
 The K timed steps are independent batches, so they are issued the way a caller with
 more than one batch to do issues them: round-robin on four HIP streams (with the runtime's
-GPU_MAX_HW_QUEUES raised from 4 to 8, so that no two of them share a hardware queue), on the
+GPU_MAX_HW_QUEUES raised from 4 to 16 by the package, so that no two of them share a hardware queue), on the
 two-solves-per-SIMD form of the wave kernel, every batch handed over AS DRAWN and issued in
 that order -- a solve holds its SIMD slot for its whole duration and durations spread 1:1.5,
 so the slots the short solves of one launch free go to the next launch.  (Round 3's issue
@@ -104,7 +104,11 @@ def cpu_baseline(sample=48):
     # the same port, one solve per worker process, on this box's CPU share
     try:
         import multiprocessing as mp
-        workers = min(16, os.cpu_count() or 1)
+        # every core this process may use, up to the GPU box's CPU share of 16 per GPU (its process guard; a one-GPU box
+        # reports 256 host cores and grants 16)
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        share = 16 * max(1, int(os.environ.get("WORLD_SIZE", "1")))
+        workers = max(1, min(avail, share))
         n_all = 24 * workers
         with mp.get_context("fork").Pool(workers) as pool:
             pool.map(_cpu_one, range(workers))  # warm-up
@@ -112,6 +116,9 @@ def cpu_baseline(sample=48):
             pool.map(_cpu_one, range(n_all))
             dta = time.perf_counter() - t0
         out["all_cores"] = {"value": n_all / dta, "unit": "solves/s", "cores": workers,
+                            "cores_available": os.cpu_count(), "cores_in_affinity_mask": avail,
+                            "cores_note": "one worker process per core of this job's CPU share (16 per GPU on the GPU boxes "
+                                          "of this pool, whatever os.cpu_count() says about the host)",
                             "sample": f"{n_all} solves of the same batch over {workers} worker processes, {dta:.1f} s"}
     except Exception as e:  # the single-core figure above is the contract; this one is extra
         out["all_cores"] = {"error": repr(e)}
@@ -171,28 +178,121 @@ def _pt_leg(rank, world, local, dev, with_cpu, use_dist=False):
                 "prefetch": ln["config"]["prefetch"], "chain_groups": ln["config"]["chain_groups"],
                 "collectives_per_iteration": ln["config"].get("collectives_per_iteration"),
                 "max_integrator_steps_per_rank": ln["config"].get("max_integrator_steps_per_rank"),
+                "exchange_ms": ln["config"].get("exchange_ms"), "exchanges_timed": ln["config"].get("exchanges_timed"),
                 **({"host_ms": ln["config"]["host_ms"]} if "host_ms" in ln["config"] else {}),
                 **({"cpu_baseline": ln["cpu_baseline"]} if "cpu_baseline" in ln else {})}
 
-    # (with a process group the warm-up spans two replica exchanges: the first collective of each shape sets RCCL up)
-    for chains, steps, warm in ((64, 30, 10), (512, 20 if world == 1 else 30, 20 if use_dist else 10)):
+    def together(ok):
+        """Every rank leaves a leg at the same place and knows whether it failed anywhere: the ranks that have
+        nothing to do in a rank-0-only leg wait HERE, visibly, not in whatever collective happens to come next."""
+        if not (use_dist and world > 1):
+            return ok
+        import torch
+        import torch.distributed as dist
+        flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return int(flag.item()) == 0
+
+    def guarded(key, fn):
         try:
-            # the 64-chain ensemble is config 3, a ONE-GPU configuration: at N > 1 rank 0 runs it alone
-            if chains == 64 and world > 1:
-                if rank == 0:
-                    out["64"] = leg(64, steps, warm, 0, 1, False, False)
-                continue
-            out[str(chains)] = leg(chains, steps, warm, rank, world, use_dist, with_cpu and chains == 64)
-            if chains == 512 and world > 1:
-                # strong scaling: the same 512-chain ensemble of the same build on ONE GPU (rank 0, the others wait
-                # at the barrier below), so that the line carries its own N = 1 figure
-                out["512"]["scaling"] = "strong"
-                if rank == 0:
-                    one = leg(512, 20, 10, 0, 1, False, False)
-                    out["512"]["one_gpu_same_build"] = one
-                    out["512"]["speedup_vs_one_gpu"] = one["ms_per_iteration"] / out["512"]["ms_per_iteration"]
+            out[key] = fn()
+            return True
         except Exception as e:  # the solves/s contract line must not depend on this leg
-            out[str(chains)] = {"error": repr(e)}
+            out[key] = {"error": repr(e)}
+            return False
+
+    if world == 1:
+        # (with a process group -- MTRPL_FORCE_DIST -- the warm-up spans two replica exchanges: the first collective of
+        # each shape sets RCCL up)
+        guarded("64", lambda: leg(64, 30, 10, rank, world, use_dist, with_cpu))
+        guarded("512", lambda: leg(512, 20, 20 if use_dist else 10, rank, world, use_dist, False))
+        return out
+    # N > 1.  (1) the strong-scaling figure: the 512-chain ensemble block-partitioned over all ranks
+    ok = guarded("512", lambda: leg(512, 30, 20, rank, world, use_dist, False))
+    if not together(ok) and "error" not in out["512"]:
+        out["512"]["error"] = "the leg failed on another rank"
+    # (2) what only rank 0 runs -- config 3 (64 chains) is a ONE-GPU configuration, and the same 512-chain ensemble of
+    # the same build on one GPU gives the line its own N = 1 figure -- while the others wait in together() below
+    if rank == 0:
+        guarded("64", lambda: leg(64, 30, 10, 0, 1, False, False))
+        if "error" not in out["512"]:
+            out["512"]["scaling"] = "strong"
+            one = {}
+            try:
+                one = leg(512, 20, 10, 0, 1, False, False)
+                out["512"]["one_gpu_same_build"] = one
+                out["512"]["speedup_vs_one_gpu"] = one["ms_per_iteration"] / out["512"]["ms_per_iteration"]
+            except Exception as e:
+                out["512"]["one_gpu_same_build"] = {"error": repr(e)}
+    together(True)
+    return out
+
+
+def _api_leg(local, dev, B=8192, n_samples=8192):
+    """What a caller of the PRODUCT API gets, host to host -- no streams, no device pointers, nothing
+    set by the caller: (a) mtrpl_solve_batch on B config-2 solves, descriptors in host memory in, samples in host memory
+    out (the C call alone into pinned and into pageable memory, and batch.solve_batch with its Python packing);
+    (b) dense_sampler.simulate -- the reference's Dense_Sample/dense_sampling.py:48-195 -- on the 6-measurement power scan
+    with IRF convolution and likelihood, samples per second."""
+    import ctypes as C
+    import torch
+    from metrotrpl_amd import _lib as L, batch, dense_sampler as DS, pt_bench, workloads as W
+    out = {}
+    ctx = L.default_context(local)
+    c = W.config2(B)
+    t = np.ascontiguousarray(c["tSteps"])
+    nt = t.shape[0]
+    d, ini = batch.build_batch(c["states"], W.indexes(), W.units(), c["iniPar"], c["thickness"], c["nx"], nt, hmax=c["hmax"],
+                               meas=c["meas"], model=c["model"], ini_mode=c["ini_mode"])
+    status = np.zeros(B, dtype=np.int32)
+
+    def c_call(buf):
+        ctx.check(L.lib().mtrpl_solve_batch(ctx.handle, B, d.ctypes.data_as(C.c_void_p), L.dptr(ini), ini.shape[0], L.dptr(t),
+                                            nt, L.dptr(buf), buf.shape[0], L.iptr(status), None))
+
+    legs = {}
+    for name, buf in (("pinned_out", L.pinned_f64(ctx, B * nt)), ("pageable_out", np.empty(B * nt))):
+        c_call(buf)  # warm-up: device scratch, streams, staging
+        t0 = time.perf_counter()
+        n_rep = 3
+        for _ in range(n_rep):
+            c_call(buf)
+        dt = (time.perf_counter() - t0) / n_rep
+        legs[name] = {"ms_per_call": dt * 1e3, "solves_per_sec": B / dt,
+                      "all_solves_ok": bool(np.all(status == 0) and np.all(np.isfinite(buf)))}
+    t0 = time.perf_counter()
+    sig = batch.solve_batch(c["states"], W.indexes(), W.units(), c["iniPar"], c["thickness"], c["nx"], t, hmax=c["hmax"],
+                            meas=c["meas"], model=c["model"], ini_mode=c["ini_mode"], ctx=ctx)
+    dt = time.perf_counter() - t0
+    legs["python_batch_solve_batch"] = {"ms_per_call": dt * 1e3, "solves_per_sec": B / dt, "all_solves_ok": bool(np.all(np.isfinite(sig)))}
+    del sig
+    out["solve_batch"] = {"solves": B, "host_chunk": int(ctx.get_option("host_chunk")), "host_streams": int(ctx.get_option("host_streams")),
+                          "solves_per_sec": legs["pinned_out"]["solves_per_sec"], **legs,
+                          "note": "PCIe-inclusive: descriptors from host memory, 8 KB of samples per solve back into host "
+                                  "memory, one blocking call; the library cuts it into sub-launches on its own streams"}
+    # (b) the dense sampler on the config-3 geometry (6 measurements, nx = 128, IRF convolution, likelihood at T = 1)
+    S = pt_bench.setup(64, dev, local)
+    eng = S["eng"]
+    names, ix = W.PARAM_NAMES, W.indexes()
+    s0 = W.initial_state()
+    lo = np.array([W.PRIOR_BOX.get(n, (s0[ix[n]], s0[ix[n]]))[0] for n in names])
+    hi = np.array([W.PRIOR_BOX.get(n, (s0[ix[n]], s0[ix[n]]))[1] for n in names])
+    X = DS.random_grid(lo, hi, [True] * len(names), n_samples, np.random.default_rng(W.SEED + 77))
+    ok = np.abs(np.log10(X[:, ix["tauN"]]) - np.log10(X[:, ix["tauP"]])) <= 2  # the reference's physics check
+    X = X[ok]
+    DS.simulate(eng, X[:2048])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    P = DS.simulate(eng, X)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    P1 = DS.simulate(eng, X[:2048], chunk=512, lanes=1)
+    dt1 = time.perf_counter() - t0
+    out["dense_sampler"] = {"samples": int(X.shape[0]), "measurements": 6, "samples_per_sec": X.shape[0] / dt,
+                            "forward_solves_per_sec": 6 * X.shape[0] / dt, "finite": int(np.isfinite(P).sum()),
+                            "one_chunk_at_a_time": {"samples_per_sec": 2048 / dt1, "same_values": bool(np.array_equal(P[:2048], P1))},
+                            "note": "dense_sampler.simulate: host array of samples in, log-likelihoods out; chunks of 1024 "
+                                    "samples (6144 solves + IRF convolution + likelihood) pipelined over three lanes"}
     return out
 
 
@@ -250,8 +350,9 @@ def main():
     global _STDOUT_FD
     # HIP maps streams onto 4 hardware queues by default: with the four streams of the timed region next to PyTorch's own,
     # two of them would share a queue and their launches serialise behind each other (measured: 330 k solves/s on four
-    # streams against 434 k on three; with 8 queues four streams give 2 % more than three).  Read when the runtime starts.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # streams against 434 k on three).  Read when the runtime starts; 16 is what the package sets for every caller
+    # (metrotrpl_amd/_lib.py, the library's own constructor): nothing here that a user of the product would not get.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     sys.stdout.flush()
     _STDOUT_FD = os.dup(1)
     os.dup2(2, 1)
@@ -282,6 +383,7 @@ def main():
                     help="the timed region only: no single-stream / sorted / fp64-linear-algebra / PT legs (profiling "
                          "runs: the kernel statistics then hold the timed kind of launch only)")
     ap.add_argument("--no-pt", action="store_true", help="skip the parallel-tempering leg")
+    ap.add_argument("--no-api", action="store_true", help="skip the host-to-host product-API leg")
     ap.add_argument("--sort-by-cost", type=int, default=0,
                     help="1: the TIMED region issues the solves of the batch longest first (order measured in a warm-up "
                          "launch of the identical batch; experiments only -- the default line reports that figure as "
@@ -299,10 +401,10 @@ def main():
     # anyway (rehearsal of the N > 1 code path on a one-GPU box)
     use_dist = world > 1 or os.environ.get("MTRPL_FORCE_DIST") == "1"
     a.use_dist = use_dist
-    a.no_cpu_baseline = a.no_cpu_baseline or world > 1
-    # CPU baseline first: its worker processes are forked before this process touches the GPU
+    # CPU baseline first: its worker processes are forked before this process touches the GPU.  At N > 1 rank 0 times
+    # it too (the other ranks wait for it in init_process_group), so that every line the driver records carries one.
     cpu = None
-    if rank == 0 and world == 1 and a.workload == "batch" and not a.no_cpu_baseline:
+    if rank == 0 and a.workload == "batch" and not a.no_cpu_baseline:
         cpu = cpu_baseline()
     import torch
     import torch.distributed as dist
@@ -403,16 +505,21 @@ def main():
             dt = float(tt.item())
         ok = all(bool((outs[q][1] == 0).all().item()) and bool(torch.isfinite(outs[q][0]).all().item())
                  for q in range(min(n_streams, a.steps)))
-        return dt, float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])), ok
+        ms = [e0.elapsed_time(e1) for e0, e1 in ev]
+        spread[0] = (float(np.min(ms)), float(np.max(ms)))
+        return dt, float(np.mean(ms)), ok
 
-    def region(dt, kern_ms, ok):
+    spread = [None]  # (min, max) of the per-launch HIP-event brackets of the last timed() call
+
+    def region(dt, kern_ms, ok, mm=None):
         return {"solves_per_sec": world * B * a.steps / dt, "ms_per_step": dt / a.steps * 1e3, "kernel_ms": kern_ms,
-                "all_solves_ok": ok}
+                **({"kernel_ms_min": mm[0], "kernel_ms_max": mm[1]} if mm else {}), "all_solves_ok": ok}
 
     # ---- (1) one launch at a time, as drawn: the latency figure and the kernel's own speed ----
-    single = fp64la = sorted_leg = None
+    single = fp64la = sorted_leg = single_mm = None
     if not a.quick and S > 1:
         single = timed(1)
+        single_mm = spread[0]
         if not user_variant:
             ctx.set_option("kernel_variant", 2)
             step()
@@ -431,8 +538,9 @@ def main():
         step(k)
     torch.cuda.synchronize()
     dt, kern_ms, ok = timed(S)
+    kern_mm = spread[0]
     if S == 1:
-        single = (dt, kern_ms, ok)
+        single, single_mm = (dt, kern_ms, ok), kern_mm
     status = d_status.cpu().numpy()
     stats = d_stats.cpu().numpy().reshape(B, 8)
     # ---- (3) the same region with each batch's solves longest first by the cost measured on the identical batch ----
@@ -515,6 +623,12 @@ def main():
             acc = accuracy_object(ctx)
         except Exception as e:  # the contract line must not depend on the fixture
             acc = {"error": repr(e)}
+    api = None
+    if rank == 0 and not a.quick and not user_variant and not a.no_api:
+        try:
+            api = _api_leg(local, dev)
+        except Exception as e:  # the contract line must not depend on this leg
+            api = {"error": repr(e)}
     pt_leg = None
     if not a.quick and not a.no_pt and not user_variant:
         del outs, d_out, d_status, d_stats
@@ -549,7 +663,7 @@ def main():
                        "device-side ordering by a cost model is gone: it bought 1.6 %)",
                        "as_drawn": not a.sort_by_cost},
             "single_stream": None if single is None else {
-                **region(*single), "note": "the same K steps back to back on one HIP stream, as drawn, one solve per SIMD "
+                **region(*single, mm=single_mm), "note": "the same K steps back to back on one HIP stream, as drawn, one solve per SIMD "
                                            "(every launch alone on the device), measured in this run"},
             "sorted_by_measured_cost": None if sorted_leg is None else {
                 **region(*sorted_leg), "note": "the timed region again with each batch's solves issued longest first, the "
@@ -563,7 +677,8 @@ def main():
             "one_launch": one_launch or None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, **pmc, "kernel": kern_name,
-                         "kernel_ms": kern_ms, "kernel_ms_brackets": "HIP events on the launch's own stream around the solve "
+                         "kernel_ms": kern_ms, "kernel_ms_min": kern_mm[0], "kernel_ms_max": kern_mm[1],
+                         "kernel_ms_brackets": "HIP events on the launch's own stream around the solve "
                          "kernel alone (since round 4 nothing else is enqueued by a launch); with several launches in flight "
                          "the bracket includes the time a launch's workgroups wait for SIMDs the other launches hold",
                          "launches_in_flight": S, "algorithmic_bytes_per_solve": A,
@@ -581,6 +696,8 @@ def main():
         if cpu is not None:
             line["cpu_baseline"] = cpu
         line["accuracy"] = acc
+        if api is not None:
+            line["api"] = api
         if pt_leg is not None:
             line["pt"] = pt_leg
         emit(line)

@@ -109,8 +109,23 @@ typedef struct mtrpl_solve_desc {
 typedef struct mtrpl_ctx mtrpl_ctx;
 
 /* ---- context ---------------------------------------------------------- */
+/* (Loading the library sets GPU_MAX_HW_QUEUES=16 in the process environment unless the caller has set it: the HIP
+ * runtime reads it at its first call and multiplexes streams onto 4 hardware queues otherwise -- the streams the
+ * pipelined mtrpl_solve_batch runs would then share queues with each other and with the caller's, and launches on one
+ * queue serialise.  A process that has already used the GPU when it loads the library keeps whatever it started with:
+ * the call is still correct, only slower -- host_streams = 0 then gives the one-launch rate back.) */
 int mtrpl_ctx_create(int device, mtrpl_ctx **ctx);
 int mtrpl_ctx_destroy(mtrpl_ctx *ctx);
+/* Frees the device memory the context holds but no longer uses (blocks its per-launch slab pool has outgrown: a slab
+ * grows geometrically, so they sum to less than twice the largest slab).  hipFree synchronises the device: call it at a
+ * quiet point (between two runs), never while launches are in flight.  Nothing inside a launch path frees. */
+int mtrpl_ctx_trim(mtrpl_ctx *ctx);
+/* Pinned host memory (hipHostMalloc).  An `out` buffer of mtrpl_solve_batch that comes from here (or from any other
+ * pinned allocation, e.g. a torch tensor with pin_memory=True) is filled by asynchronous device-to-host copies while
+ * later sub-launches compute; a pageable one goes through a pinned staging ring and a host copy.  Freed by
+ * mtrpl_host_free, or with the context. */
+int mtrpl_host_alloc(mtrpl_ctx *ctx, int64_t bytes, void **out);
+int mtrpl_host_free(mtrpl_ctx *ctx, void *p);
 const char *mtrpl_last_error(const mtrpl_ctx *ctx);
 const char *mtrpl_version(void);
 /* Integrator options.  Unknown key -> MTRPL_ERR_BAD_ARG.
@@ -181,6 +196,11 @@ const char *mtrpl_version(void);
  *                                     temperatures no sum depends on the block size).  Measured on three chain groups of a
  *                                     512-chain ensemble: 6.7 / 6.9 / 8.5 ms per iteration with 1 / 2 / 4 waves per block,
  *                                     8.5 with twelve
+ *   host_chunk, host_streams          mtrpl_solve_batch (host pointers) with more than host_chunk (2048; / 2, / 4 for the
+ *                                     two- and four-wave kernels of nx > 128) solves runs as sub-launches of that size,
+ *                                     round-robin on host_streams (2; 0 = always one blocking launch, at most 8) streams
+ *                                     the context owns, each sub-launch's samples copied back while the later ones
+ *                                     compute.  Same results bit for bit
  *   precision                         64 (product) | 32 (fp32 instantiation of the team kernel: precision sweep only) */
 int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value);
 int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value);
@@ -189,7 +209,12 @@ int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value);
 /* replaces forward_solver.solve (forward_solver.py:41-203) for B calls at once.
  * stats (may be NULL): 8 int32 per solve = steps, rhs evals, factorisations,
  * jacobian refreshes, rejected steps, newton failures, final order, residency of the solve on
- * its SIMD in units of 16 shader-clock ticks. */
+ * its SIMD in units of 16 shader-clock ticks.
+ * Blocking; a big batch is pipelined INSIDE the call (options host_chunk / host_streams above): sub-launches on the
+ * context's own streams so that the SIMD slots the short solves of one free go to the next, device-to-host copies of
+ * finished sub-launches under the later ones' compute.  The caller needs no streams and sets nothing.  (Needs the
+ * descriptors to fill `out` in ascending order -- out_off non-decreasing from one sub-launch to the next, as every
+ * packer of this repo lays them out; otherwise the call falls back to one launch.) */
 int mtrpl_solve_batch(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *descs,
                       const double *ini, int64_t n_ini, const double *tsteps, int64_t n_t,
                       double *out, int64_t n_out, int32_t *status, int32_t *stats);

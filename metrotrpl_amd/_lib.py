@@ -8,6 +8,11 @@ import os
 import subprocess
 import threading
 
+# Read by the HIP runtime at its first call (not at import): the pipelined host path and the engines' side streams need
+# more than the default 4 hardware queues (include/metrotrpl_amd.h, "context").  The library's own constructor does the
+# same for C callers; here it also covers `import torch` + a GPU call before the library is loaded.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
@@ -58,6 +63,9 @@ _vp = C.c_void_p
 SIGNATURES = {
     "mtrpl_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "mtrpl_ctx_destroy": (C.c_int, [_vp]),
+    "mtrpl_ctx_trim": (C.c_int, [_vp]),
+    "mtrpl_host_alloc": (C.c_int, [_vp, C.c_int64, C.POINTER(_vp)]),
+    "mtrpl_host_free": (C.c_int, [_vp, _vp]),
     "mtrpl_last_error": (C.c_char_p, [_vp]),
     "mtrpl_version": (C.c_char_p, []),
     "mtrpl_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
@@ -182,6 +190,49 @@ class Context:
         v = C.c_double()
         self.check(lib().mtrpl_get_option(self._h, key.encode(), C.byref(v)))
         return v.value
+
+    def trim(self):
+        """Free device memory the context no longer uses (mtrpl_ctx_trim: synchronises the device -- quiet points only)."""
+        self.check(lib().mtrpl_ctx_trim(self._h))
+
+
+class PinnedBuffer:
+    """`nbytes` of pinned host memory from the library (mtrpl_host_alloc) as the base object of numpy arrays
+    (`np.asarray(buf)` is a float64 view that keeps `buf` alive).  mtrpl_solve_batch copies straight into such memory
+    while later sub-launches compute.  Pinning is slow (page by page), so freed buffers go back to a small per-context
+    free-list by size instead of to the runtime."""
+    _KEEP_BYTES = 1 << 30
+
+    def __init__(self, ctx, nbytes):
+        nbytes = max(8, int(nbytes) + (-int(nbytes)) % 8)
+        self.ctx, self.nbytes = ctx, nbytes
+        pool = ctx.__dict__.setdefault("_pinned_free", {})
+        have = pool.get(nbytes)
+        if have:
+            self.ptr = have.pop()
+        else:
+            p = _vp()
+            ctx.check(lib().mtrpl_host_alloc(ctx.handle, nbytes, C.byref(p)))
+            self.ptr = p.value
+        self.__array_interface__ = {"data": (self.ptr, False), "shape": (nbytes // 8,), "typestr": "<f8", "version": 3}
+
+    def __del__(self):
+        try:
+            ctx = self.ctx
+            if not getattr(ctx, "_h", None):
+                return  # the context went first and took its pinned memory with it
+            pool = ctx.__dict__.setdefault("_pinned_free", {})
+            if sum(k * len(v) for k, v in pool.items()) + self.nbytes <= self._KEEP_BYTES:
+                pool.setdefault(self.nbytes, []).append(self.ptr)
+            else:
+                lib().mtrpl_host_free(ctx.handle, self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_f64(ctx, n):
+    """float64 array of n elements in pinned host memory (contents undefined)."""
+    return np.asarray(PinnedBuffer(ctx, 8 * int(n)))[:int(n)]
 
 
 _default_ctx = {}

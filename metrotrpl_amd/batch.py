@@ -91,7 +91,9 @@ def solve_batch(states, indexes, units, iniPar, thickness, nx, tSteps, hmax=4.0,
     d, ini = build_batch(states, indexes, units, iniPar, thickness, nx, nt, hmax, meas, model, ini_mode,
                          RTOL, ATOL, min_y)
     B = d.shape[0]
-    out = np.empty(B * nt)
+    # big batches are pipelined inside the call (sub-launches on the context's streams): into pinned memory their
+    # samples come back by asynchronous copies under the later sub-launches' compute
+    out = L.pinned_f64(ctx, B * nt) if B * nt >= (1 << 20) else np.empty(B * nt)
     status = np.zeros(B, dtype=np.int32)
     stats = np.zeros((B, 8), dtype=np.int32)
     ctx.check(L.lib().mtrpl_solve_batch(ctx.handle, B, d.ctypes.data_as(C.c_void_p), L.dptr(ini), ini.shape[0],

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <string>
@@ -58,6 +59,19 @@ struct mtrpl_ctx {
     int two_per_simd_min_batch = 1025;  // kernel_variant 0: launches of at least this many std / nx <= 128 solves use
                                         // the two-solves-per-SIMD build of the wave kernel (more than one solve per
                                         // SIMD anyway), smaller ones the one-per-SIMD build: same results
+    // The pipelined host-pointer solve (mtrpl_solve_batch with more than host_chunk solves): streams the context owns,
+    // a ring of pinned staging slots for callers whose output buffer is pageable, one event per slot.
+    static constexpr int kPipeMax = 8;
+    hipStream_t pipe[kPipeMax] = {};
+    int n_pipe = 0;
+    hipEvent_t pipe_in = nullptr;
+    std::vector<hipEvent_t> pipe_done;
+    void *stage = nullptr;
+    size_t stage_cap = 0;
+    int host_chunk = 2048;   // solves per sub-launch at nx <= 128 (/ 2, / 4 for the two- and four-wave kernels)
+    int host_streams = 2;    // sub-launches in flight (measured at B = 8192: 2 x 2048 520 k solves/s, 4 x 1024 500 k, one
+                             // launch 495 k; and the fewer streams, the smaller the chance that two of them share a hardware queue)
+    std::vector<void *> host_allocs;  // mtrpl_host_alloc
 };
 
 #define HIP_TRY(ctx, expr)                                                                   \
@@ -312,10 +326,11 @@ int check_descs(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d, int64_t n_
 
 // a slab of at least `need` bytes that no in-flight launch on another stream is using.  The pool holds at most
 // one idle slab that is too small: growing REPLACES the smallest idle one instead of adding to it, so that a
-// sequence of launches of varying size does not accumulate stale slabs.  The outgrown block is not freed here --
-// hipFree synchronises the whole device, i.e. stalls every other stream's launches -- but parked in ctx->retired
-// (freed with the context, or here once more than kRetiredMax bytes are parked).
-constexpr size_t kRetiredMax = (size_t)2 << 30;
+// sequence of launches of varying size does not accumulate stale slabs.  A slab grows GEOMETRICALLY (to at least
+// 1.5 x its old size), so a caller whose launches grow step by step retires a block only every few steps and the
+// parked memory stays below twice the largest slab; the outgrown block is not freed here -- hipFree synchronises
+// the whole device, i.e. stalls every other stream's launches in the middle of a launch -- but parked in
+// ctx->retired and freed at a quiet point the CALLER names: mtrpl_ctx_trim, or with the context.
 int take_slab(mtrpl_ctx *ctx, std::deque<Slab> &pool, size_t need, hipStream_t s, Slab **out)
 {
     Slab *pick = nullptr, *small = nullptr;
@@ -336,18 +351,13 @@ int take_slab(mtrpl_ctx *ctx, std::deque<Slab> &pool, size_t need, hipStream_t s
     }
     if (!pick) {
         void *p = nullptr;
+        if (small) need = std::max(need, small->bytes + small->bytes / 2);
         HIP_TRY(ctx, hipMalloc(&p, need));
         if (small) {  // idle (or ordered before us on this stream) and too small
             Slab old;
             old.p = small->p;
             old.bytes = small->bytes;
             ctx->retired.push_back(old);
-            size_t parked = 0;
-            for (const Slab &r : ctx->retired) parked += r.bytes;
-            if (parked > kRetiredMax) {
-                for (Slab &r : ctx->retired) (void)hipFree(r.p);
-                ctx->retired.clear();
-            }
             small->p = p;
             small->bytes = need;
             pick = small;
@@ -428,7 +438,15 @@ int launch_team_any(mtrpl_ctx *ctx, hipStream_t s, int64_t B, const mtrpl_solve_
 
 extern "C" {
 
-const char *mtrpl_version(void) { return "metrotrpl_amd 0.2 (gfx950)"; }
+const char *mtrpl_version(void) { return "metrotrpl_amd 0.3 (gfx950)"; }
+
+// HIP multiplexes streams onto 4 hardware queues by default; the pipelined host path runs streams of its own next to
+// whatever the caller has (PyTorch's streams, other contexts), and two streams on one queue serialise their launches
+// (measured, B = 8192 host to host: 520 k solves/s, 390-430 k when two of the sub-launch streams share a queue -- which
+// happened with 8 queues as soon as the process owned ten streams, and not with 16: profiles/r05_api_queues.txt).  The
+// runtime reads GPU_MAX_HW_QUEUES when it starts, i.e. at the first HIP call of the process: set here, when the library
+// is LOADED, unless the caller has set it.  A process that has used the GPU before loading this library keeps its own.
+__attribute__((constructor)) static void mtrpl_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 int mtrpl_ctx_create(int device, mtrpl_ctx **out)
 {
@@ -461,6 +479,11 @@ int mtrpl_ctx_destroy(mtrpl_ctx *ctx)
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     for (Slab &sl : ctx->retired) (void)hipFree(sl.p);
+    for (int q = 0; q < ctx->n_pipe; ++q) (void)hipStreamDestroy(ctx->pipe[q]);
+    if (ctx->pipe_in) (void)hipEventDestroy(ctx->pipe_in);
+    for (hipEvent_t e : ctx->pipe_done) (void)hipEventDestroy(e);
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
+    for (void *p : ctx->host_allocs) (void)hipHostFree(p);
     for (int k = 0; k < mtrpl_ctx::kScratch; ++k)
         if (ctx->scratch[k]) (void)hipFree(ctx->scratch[k]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -523,6 +546,12 @@ int mtrpl_set_option(mtrpl_ctx *ctx, const char *key, double value)
         // removed in round 2 (the Jacobian is always refreshed at a refactorisation): accepted and ignored
     } else if (k == "two_per_simd_min_batch") {
         ctx->two_per_simd_min_batch = (int)value;
+    } else if (k == "host_chunk") {
+        if (!(value >= 1)) return bad(ctx, MTRPL_ERR_BAD_ARG, "host_chunk must be >= 1");
+        ctx->host_chunk = (int)value;
+    } else if (k == "host_streams") {
+        if (value < 0 || value > mtrpl_ctx::kPipeMax) return bad(ctx, MTRPL_ERR_BAD_ARG, "host_streams must be 0 (one blocking launch) ... 8");
+        ctx->host_streams = (int)value;
     } else if (k == "loglik_wave_blocks") {
         if (value != 0 && value != 1 && value != 2 && value != 4)
             return bad(ctx, MTRPL_ERR_BAD_ARG, "loglik_wave_blocks must be 0 (twelve waves per trace), 1, 2 or 4 (waves per block)");
@@ -547,15 +576,31 @@ int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value)
     if (k == "kernel_variant") *value = ctx->kernel_variant;
     else if (k == "two_per_simd_min_batch") *value = ctx->two_per_simd_min_batch;
     else if (k == "loglik_wave_blocks") *value = ctx->loglik_wave_blocks;
+    else if (k == "host_chunk") *value = ctx->host_chunk;
+    else if (k == "host_streams") *value = ctx->host_streams;
     else if (k == "precision") *value = ctx->precision;
     else if (k == "fresh_jac") *value = 0.0;  // accepted and ignored (set_option)
     else return MTRPL_ERR_BAD_ARG;
     return MTRPL_OK;
 }
 
+static int launch_solves(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
+                         const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats, int32_t max_nx,
+                         int32_t model, void *stream, int64_t in_flight);
+
 int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
                           const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats, int32_t max_nx,
                           int32_t model, void *stream)
+{
+    return launch_solves(ctx, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, max_nx, model, stream, B);
+}
+
+// in_flight: the solves the caller has (or is about to have) on the device together with this launch -- what the choice
+// between the one- and the two-solves-per-SIMD build of the wave kernel goes by (a sub-launch of the pipelined host path
+// says the size of the whole call)
+static int launch_solves(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
+                         const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats, int32_t max_nx,
+                         int32_t model, void *stream, int64_t in_flight)
 {
     if (!ctx) return MTRPL_ERR_BAD_ARG;
     if (B <= 0) return MTRPL_OK;
@@ -582,7 +627,7 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
     //   wave  (2): fp64 blocks and an fp64 re-solve: the exact linear algebra, one solve per SIMD
     int variant = ctx->kernel_variant;
     if (variant == 0)
-        variant = (B >= ctx->two_per_simd_min_batch) ? 3 : 6;
+        variant = (std::max(B, in_flight) >= ctx->two_per_simd_min_batch) ? 3 : 6;
     const bool ct = default_tune(ctx->tune);
 #define MTRPL_WAVE(KERNEL)                                                                                            \
     do {                                                                                                              \
@@ -619,6 +664,50 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
     return MTRPL_OK;
 }
 
+namespace {
+// Is p memory the device can copy to on its own (hipHostMalloc / hipHostRegister: mtrpl_host_alloc, torch's pinned
+// tensors)?  Pageable memory makes hipMemcpyAsync a blocking, staged copy.
+bool host_pinned(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // (older runtimes report pageable memory as an error: not sticky)
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+int pipe_setup(mtrpl_ctx *ctx, int ns, int nslots, size_t slot_bytes)
+{
+    while (ctx->n_pipe < ns) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->pipe[ctx->n_pipe], hipStreamNonBlocking));
+        ctx->n_pipe++;
+    }
+    if (!ctx->pipe_in) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pipe_in, hipEventDisableTiming));
+    while ((int)ctx->pipe_done.size() < nslots) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->pipe_done.push_back(e);
+    }
+    const size_t need = (size_t)nslots * slot_bytes;
+    if (need > ctx->stage_cap) {
+        if (ctx->stage) (void)hipHostFree(ctx->stage);
+        ctx->stage = nullptr;
+        ctx->stage_cap = 0;
+        HIP_TRY(ctx, hipHostMalloc(&ctx->stage, need + need / 4, hipHostMallocDefault));
+        ctx->stage_cap = need + need / 4;
+    }
+    return MTRPL_OK;
+}
+}  // namespace
+
+// Host pointers in, host pointers out.  Up to host_chunk solves: one launch on the context's stream, as ever.  More: the
+// batch is cut into sub-launches of host_chunk solves, issued round-robin on host_streams streams the context owns -- a
+// solve holds its SIMD slot for its whole duration and durations spread 1 : 1.5, so the slots the short solves of one
+// sub-launch free go to the next one's (1.3x the rate of one big launch) -- and the samples of a
+// finished sub-launch travel back while the later ones compute: straight into `out` when that is pinned memory
+// (mtrpl_host_alloc), through a ring of pinned staging slots and a host copy otherwise.  Same results as the blocking
+// path bit for bit (a solve gives the same samples whatever launch it travels in).
 int mtrpl_solve_batch(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *descs, const double *ini, int64_t n_ini,
                       const double *tsteps, int64_t n_t, double *out, int64_t n_out, int32_t *status, int32_t *stats)
 {
@@ -635,20 +724,140 @@ int mtrpl_solve_batch(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *descs, 
     HIP_TRY(ctx, dout.alloc(sizeof(double) * (size_t)n_out));
     HIP_TRY(ctx, dst.alloc(sizeof(int32_t) * B));
     HIP_TRY(ctx, dstat.alloc(sizeof(int32_t) * 8 * B));
-    hipStream_t s = ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(dd.p, descs, sizeof(mtrpl_solve_desc) * B, hipMemcpyHostToDevice, s));
-    if (n_ini > 0 && ini) HIP_TRY(ctx, hipMemcpyAsync(di.p, ini, sizeof(double) * (size_t)n_ini, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(dt.p, tsteps, sizeof(double) * (size_t)n_t, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemsetAsync(dout.p, 0, sizeof(double) * (size_t)n_out, s));
     int32_t max_nx = 0;
     for (int64_t k = 0; k < B; ++k) max_nx = std::max(max_nx, descs[k].nx);
-    rc = mtrpl_solve_batch_dev(ctx, B, dd.as<mtrpl_solve_desc>(), di.as<double>(), dt.as<double>(), dout.as<double>(),
-                               dst.as<int32_t>(), dstat.as<int32_t>(), max_nx, descs[0].model, s);
+
+    // ---- the sub-launches and the stretch of `out` each one completes ----
+    const int64_t chunk = std::max<int64_t>(1, ctx->host_chunk / (max_nx > 256 ? 4 : (max_nx > 128 ? 2 : 1)));
+    const int64_t nchunks = (B + chunk - 1) / chunk;
+    const int ns = (int)std::min<int64_t>(std::max(1, std::min(ctx->host_streams, (int)mtrpl_ctx::kPipeMax)), nchunks);
+    std::vector<int64_t> upto;  // sub-launch j completes out[upto[j-1], upto[j]) -- if the descriptors fill `out` in order
+    bool pipelined = nchunks > 1 && ctx->host_streams > 0;
+    if (pipelined) {
+        int64_t prev_end = 0;
+        for (int64_t j = 0; j < nchunks && pipelined; ++j) {
+            int64_t lo = INT64_MAX, hi = 0;
+            for (int64_t k = j * chunk; k < std::min(B, (j + 1) * chunk); ++k) {
+                lo = std::min(lo, descs[k].out_off);
+                hi = std::max(hi, descs[k].out_off + descs[k].nt);
+            }
+            if (lo < prev_end) pipelined = false;  // a later sub-launch writes below an earlier one's range: no order to stream in
+            upto.push_back(j == nchunks - 1 ? n_out : hi);
+            prev_end = hi;
+        }
+    }
+    if (!pipelined) {
+        hipStream_t s = ctx->stream;
+        HIP_TRY(ctx, hipMemcpyAsync(dd.p, descs, sizeof(mtrpl_solve_desc) * B, hipMemcpyHostToDevice, s));
+        if (n_ini > 0 && ini) HIP_TRY(ctx, hipMemcpyAsync(di.p, ini, sizeof(double) * (size_t)n_ini, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(dt.p, tsteps, sizeof(double) * (size_t)n_t, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemsetAsync(dout.p, 0, sizeof(double) * (size_t)n_out, s));
+        rc = mtrpl_solve_batch_dev(ctx, B, dd.as<mtrpl_solve_desc>(), di.as<double>(), dt.as<double>(), dout.as<double>(),
+                                   dst.as<int32_t>(), dstat.as<int32_t>(), max_nx, descs[0].model, s);
+        if (rc != MTRPL_OK) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpyAsync(status, dst.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+        if (stats) HIP_TRY(ctx, hipMemcpyAsync(stats, dstat.p, sizeof(int32_t) * 8 * B, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        return MTRPL_OK;
+    }
+
+    const bool direct = host_pinned(out);
+    const int nslots = direct ? 0 : (int)std::min<int64_t>(nchunks, 2 * ns);
+    size_t slot_bytes = 0;
+    for (int64_t j = 0; j < nchunks; ++j)
+        slot_bytes = std::max(slot_bytes, sizeof(double) * (size_t)(upto[j] - (j ? upto[j - 1] : 0)));
+    rc = pipe_setup(ctx, ns, nslots, slot_bytes);
     if (rc != MTRPL_OK) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipMemcpyAsync(status, dst.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
-    if (stats) HIP_TRY(ctx, hipMemcpyAsync(stats, dstat.p, sizeof(int32_t) * 8 * B, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipStreamSynchronize(s));
+    // inputs on the first stream; the others start behind them
+    hipStream_t s0 = ctx->pipe[0];
+    HIP_TRY(ctx, hipMemcpyAsync(dd.p, descs, sizeof(mtrpl_solve_desc) * B, hipMemcpyHostToDevice, s0));
+    if (n_ini > 0 && ini) HIP_TRY(ctx, hipMemcpyAsync(di.p, ini, sizeof(double) * (size_t)n_ini, hipMemcpyHostToDevice, s0));
+    HIP_TRY(ctx, hipMemcpyAsync(dt.p, tsteps, sizeof(double) * (size_t)n_t, hipMemcpyHostToDevice, s0));
+    HIP_TRY(ctx, hipMemsetAsync(dout.p, 0, sizeof(double) * (size_t)n_out, s0));  // (gaps between traces read as zero, as ever)
+    HIP_TRY(ctx, hipEventRecord(ctx->pipe_in, s0));
+    for (int q = 1; q < ns; ++q) HIP_TRY(ctx, hipStreamWaitEvent(ctx->pipe[q], ctx->pipe_in, 0));
+
+    int fail = MTRPL_OK;
+    auto drain = [&](int64_t j) -> int {  // sub-launch j's samples from its staging slot into the caller's buffer
+        const int slot = (int)(j % nslots);
+        HIP_TRY(ctx, hipEventSynchronize(ctx->pipe_done[slot]));
+        const int64_t a = j ? upto[j - 1] : 0;
+        std::memcpy(out + a, static_cast<char *>(ctx->stage) + (size_t)slot * slot_bytes, sizeof(double) * (size_t)(upto[j] - a));
+        return MTRPL_OK;
+    };
+    int64_t drained = 0;
+    for (int64_t j = 0; j < nchunks && fail == MTRPL_OK; ++j) {
+        if (!direct && j >= nslots) {  // the slot this sub-launch copies into is free once its previous user is out
+            fail = drain(j - nslots);
+            drained = j - nslots + 1;
+            if (fail != MTRPL_OK) break;
+        }
+        hipStream_t s = ctx->pipe[j % ns];
+        const int64_t k0 = j * chunk, nb = std::min(B, k0 + chunk) - k0;
+        fail = launch_solves(ctx, nb, dd.as<mtrpl_solve_desc>() + k0, di.as<double>(), dt.as<double>(), dout.as<double>(),
+                             dst.as<int32_t>() + k0, dstat.as<int32_t>() + 8 * k0, max_nx, descs[0].model, s, B);
+        if (fail != MTRPL_OK) break;
+        const int64_t a = j ? upto[j - 1] : 0;
+        void *dst_host = direct ? static_cast<void *>(out + a)
+                                : static_cast<void *>(static_cast<char *>(ctx->stage) + (size_t)(j % nslots) * slot_bytes);
+        hipError_t e = hipMemcpyAsync(dst_host, dout.as<double>() + a, sizeof(double) * (size_t)(upto[j] - a),
+                                      hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && !direct) e = hipEventRecord(ctx->pipe_done[j % nslots], s);
+        if (e != hipSuccess) {
+            ctx->err = std::string("pipelined solve, device-to-host copy: ") + hipGetErrorString(e);
+            fail = MTRPL_ERR_DEVICE;
+        }
+    }
+    if (!direct)
+        for (int64_t j = drained; j < nchunks && fail == MTRPL_OK; ++j) fail = drain(j);
+    // nothing of this call may be in flight when it returns, whatever happened above (the buffers are the context's)
+    for (int q = 0; q < ns; ++q) {
+        const hipError_t e = hipStreamSynchronize(ctx->pipe[q]);
+        if (e != hipSuccess && fail == MTRPL_OK) {
+            ctx->err = std::string("pipelined solve, hipStreamSynchronize: ") + hipGetErrorString(e);
+            fail = MTRPL_ERR_DEVICE;
+        }
+    }
+    if (fail != MTRPL_OK) return fail;
+    HIP_TRY(ctx, hipMemcpy(status, dst.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+    if (stats) HIP_TRY(ctx, hipMemcpy(stats, dstat.p, sizeof(int32_t) * 8 * B, hipMemcpyDeviceToHost));
+    return MTRPL_OK;
+}
+
+// Pinned host memory from the library (hipHostMalloc): an `out` buffer of mtrpl_solve_batch that comes from here is
+// filled by asynchronous device-to-host copies, without the staging pass.  Freed by mtrpl_host_free or with the context.
+int mtrpl_host_alloc(mtrpl_ctx *ctx, int64_t bytes, void **out)
+{
+    if (!ctx || !out || bytes <= 0) return bad(ctx, MTRPL_ERR_BAD_ARG, "bad argument");
+    *out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void *p = nullptr;
+    HIP_TRY(ctx, hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault));
+    ctx->host_allocs.push_back(p);
+    *out = p;
+    return MTRPL_OK;
+}
+
+int mtrpl_host_free(mtrpl_ctx *ctx, void *p)
+{
+    if (!ctx) return MTRPL_ERR_BAD_ARG;
+    if (!p) return MTRPL_OK;
+    auto it = std::find(ctx->host_allocs.begin(), ctx->host_allocs.end(), p);
+    if (it == ctx->host_allocs.end()) return bad(ctx, MTRPL_ERR_BAD_ARG, "not a pointer from mtrpl_host_alloc of this context");
+    ctx->host_allocs.erase(it);
+    HIP_TRY(ctx, hipHostFree(p));
+    return MTRPL_OK;
+}
+
+// Frees what the context holds but no longer uses -- the device blocks its slab pool has outgrown.  hipFree synchronises
+// the device, so this belongs at a quiet point of the caller's choosing (between two runs), never inside a launch path.
+int mtrpl_ctx_trim(mtrpl_ctx *ctx)
+{
+    if (!ctx) return MTRPL_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (Slab &r : ctx->retired) (void)hipFree(r.p);
+    ctx->retired.clear();
     return MTRPL_OK;
 }
 

@@ -24,12 +24,45 @@ def random_grid(min_X, max_X, do_log, num_samples, rng=None):
     return grid
 
 
-def simulate(engine, X, temperature=1.0, chunk=512):
+def simulate(engine, X, temperature=1.0, chunk=1024, lanes=3):
     """Log-likelihood of every sample row of X (summed over the engine's measurements).
-    `engine` is a metrotrpl_amd.likelihood.LikelihoodEngine."""
+    `engine` is a metrotrpl_amd.likelihood.LikelihoodEngine.
+
+    The samples are independent, so the chunks are pipelined: up to `lanes` chunks are in flight on streams of their
+    own (clones of the engine: same device constants, own launch buffers) -- while chunk k's likelihood kernel runs and
+    its table travels back, the solves of chunks k+1, ... hold the SIMDs, and the slots a chunk's short solves free go
+    to the next chunk's (a solve holds its SIMD for its whole duration; durations spread 1 : 1.5).  lanes=1: one chunk
+    at a time, each waited for (round 4's loop); the values do not depend on `lanes` or `chunk`."""
     X = np.atleast_2d(np.asarray(X, dtype=float))
-    P = np.empty(X.shape[0])
-    for a in range(0, X.shape[0], chunk):
-        table = engine.eval(X[a:a + chunk], [temperature])   # [c, M, 1]
-        P[a:a + chunk] = table[:, :, 0].sum(axis=1)
+    n = X.shape[0]
+    P = np.empty(n)
+    starts = list(range(0, n, chunk))
+    lanes = max(1, min(int(lanes), len(starts)))
+    if lanes == 1:
+        for a in starts:
+            table = engine.eval(X[a:a + chunk], [temperature])   # [c, M, 1]
+            P[a:a + chunk] = table[:, :, 0].sum(axis=1)
+        return P
+    from . import _lib as L
+    pool = engine.__dict__.setdefault("_sampler_lanes", [])
+    while len(pool) < lanes:
+        pool.append(engine.clone())
+    streams = L.shared_streams(engine.dev, lanes)
+    # every chunk shares the device with the other lanes' chunks: more solves than SIMDs in flight whatever a chunk's
+    # size, so each launch takes the two-solves-per-SIMD build of the wave kernel (same results)
+    keep = engine.ctx.get_option("two_per_simd_min_batch")
+    engine.ctx.set_option("two_per_simd_min_batch", 1)
+    try:
+        pending = [None] * lanes
+        for k, a in enumerate(starts):
+            q = k % lanes
+            if pending[q] is not None:
+                a0, h = pending[q]
+                P[a0:a0 + chunk] = h.result()[:, :, 0].sum(axis=1)
+            pending[q] = (a, pool[q].eval_async(X[a:a + chunk], [temperature], streams[q]))
+        order = sorted((p for p in pending if p is not None), key=lambda p: p[0])
+        for a0, h in order:
+            P[a0:a0 + chunk] = h.result()[:, :, 0].sum(axis=1)
+    finally:
+        engine.ctx.set_option("two_per_simd_min_batch", keep)
     return P

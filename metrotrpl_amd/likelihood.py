@@ -74,6 +74,7 @@ class LikelihoodEngine:
         self.sort_by_cost = bool(sort_by_cost)
         self.parts = max(1, int(parts))
         self.split_min, self.sort_min = int(split_min), int(sort_min)
+        self.packed_sort_min = self.sort_min  # plan_packed's threshold; a caller that wants EVERY packed launch ordered sets 0
         self._stage = []  # pinned staging buffers of the descriptor upload: [tensor, event] pairs, used in turn
         self._side = []
         self._cap = 0
@@ -278,7 +279,7 @@ class LikelihoodEngine:
         parts = self.parts if n > self.split_min else 1
         cuts = [(R * p // parts) * self.M for p in range(parts + 1)]
         order = None
-        if self.sort_by_cost and n > self.sort_min:
+        if self.sort_by_cost and n > self.packed_sort_min:
             cost = self._row_cost(n)
             if cost is None:
                 cost = np.repeat(1.0 + states[:, self.indexes["tauP"]] / states[:, self.indexes["tauN"]], self.M)
@@ -411,6 +412,55 @@ class LikelihoodEngine:
         ll = self.launch(d_T, len(T))
         torch.cuda.synchronize()
         return ll.cpu().numpy().reshape(-1, self.M, len(T))
+
+    # ---- several evaluations in flight: lanes ---------------------------------------------------------------
+    def clone(self):
+        """A second LANE of the same problem: shares everything that is constant on the device (time grids, data, IRF
+        tables, descriptor templates) and owns what one launch writes (simulated traces, status, table, staging), so that
+        evaluations on different lanes may be in flight on different streams (`eval_async`)."""
+        import copy
+        c = copy.copy(self)
+        c._stage, c._side, c._cap, c._ticks, c.timing = [], [], 0, None, None
+        for k in ("d_sig", "d_status", "d_stats", "d_ll", "_prev_order", "_prev_states", "_packed", "_lane_out", "_lane_T"):
+            c.__dict__.pop(k, None)
+        return c
+
+    def eval_async(self, states, temperatures=(1.0,), stream=None):
+        """`eval` without the wait: upload, solve, likelihood and the copy of the table to pinned host memory are
+        enqueued on `stream` (a torch stream; default: the current one) and a handle comes back at once;
+        `handle.result()` waits for that lane only and returns the [C, M, nT] table.  One evaluation per lane at a time:
+        call `result()` before the next `eval_async` of the same engine, use `clone()`s for more in flight."""
+        torch = self.torch
+        T = np.ascontiguousarray(np.atleast_1d(temperatures), dtype=np.float64)
+        st = stream or torch.cuda.current_stream()
+        with torch.cuda.stream(st):
+            cached = getattr(self, "_lane_T", None)
+            if cached is None or cached[0].shape != T.shape or not np.array_equal(cached[0], T):
+                cached = self._lane_T = (T.copy(), torch.from_numpy(T).to(self.dev))
+            self.upload(states)
+            ll = self.launch(cached[1], len(T), st)
+            n = ll.shape[0]
+            host = getattr(self, "_lane_out", None)
+            if host is None or host.shape[0] < n:
+                host = self._lane_out = torch.empty(n, dtype=torch.float64, pin_memory=True)
+            host[:n].copy_(ll, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(st)
+        return _Pending(done, host, n, (-1, self.M, len(T)))
+
+
+class _Pending:
+    """An evaluation in flight (LikelihoodEngine.eval_async)."""
+
+    def __init__(self, done, host, n, shape):
+        self._done, self._host, self._n, self._shape = done, host, n, shape
+
+    def ready(self):
+        return self._done.query()
+
+    def result(self):
+        self._done.synchronize()
+        return self._host[:self._n].numpy().reshape(self._shape).copy()
 
 
 def fittable_indexes(shared_fields):

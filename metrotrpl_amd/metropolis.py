@@ -181,6 +181,18 @@ def _start_logging(log_dir, name, verbose):
     return logger, handler
 
 
+def _stretches(start, stop, every):
+    """(a, b, last) for the stretches [a, b) a run from `start` to `stop` is cut into when it checkpoints after every
+    `every` iterations: b = min(a + every, stop); the stretch that reaches `stop` is the last (metropolis.py:388-412)."""
+    a = start
+    while True:
+        b = stop if every <= 0 else min(a + every, stop)
+        yield a, b, b == stop
+        if b == stop:
+            return
+        a = b
+
+
 def metro(sim_info, iniPar, e_data, MCMC_fields, param_info, verbose=False, export_path="", **kwargs):
     """Drop-in for metropolis.metro (:283-476).  Extra keyword arguments:
     rng_mode ("serial" | "mpi", default "mpi" -- the reference's production mode is one MPI
@@ -264,41 +276,43 @@ def metro(sim_info, iniPar, e_data, MCMC_fields, param_info, verbose=False, expo
     walk = Walk(ef, uf, RNG, gather, rng_mode=rng_mode, logger=logger,
                 serial_swap_aliasing=kwargs.get("serial_swap_aliasing", False))
     walk.set_random_state(MS_list.random_state)
-    need_initial_state = load_checkpoint is None
-    ending_iter = min(starting_iter + checkpoint_freq, num_iters)
-    while ending_iter <= num_iters:
-        logger.info(f"Simulating from {starting_iter} to {ending_iter}")
-        walk.run(states, logll, accept, starting_iter, ending_iter, need_initial_state=need_initial_state)
-        if ending_iter == num_iters:
-            break
-        if rng_mode == "mpi":
-            # main_metro_loop counts per segment and metro() adds every segment's counts before it
-            # saves (metropolis.py:431-437); the serial loop's counts are only added after the last
-            # segment (:464-466)
-            MS_list.H.swap_attempts = MS_list.H.swap_attempts + walk.swap_attempts
-            MS_list.H.swap_accept = MS_list.H.swap_accept + walk.swap_accept
-            walk.swap_attempts[:] = 0
-            walk.swap_accept[:] = 0
-        MS_list.latest_iter = ending_iter
+    target = os.path.join(ef["output_path"], export_path)
+
+    def fold_swap_counts():
+        MS_list.H.swap_attempts = MS_list.H.swap_attempts + walk.swap_attempts
+        MS_list.H.swap_accept = MS_list.H.swap_accept + walk.swap_accept
+        walk.swap_attempts[:] = 0
+        walk.swap_accept[:] = 0
+
+    def snapshot(upto):
+        """What a checkpoint holds (metropolis.py:402-412, :431-446, :464-472): history, the iteration reached, ONE
+        generator state."""
+        MS_list.latest_iter = upto
         MS_list.H.pack(states, logll, accept)
         MS_list.random_state = walk.random_state()
-        if rank == 0:
-            logger.info(f"Saving checkpoint at k={ending_iter}")
-            MS_list.checkpoint(os.path.join(ef["output_path"], export_path))
-        need_initial_state = False
-        starting_iter = ending_iter
-        ending_iter = min(ending_iter + checkpoint_freq, num_iters)
-    logger.info(f"Rank {rank} took {perf_counter() - clock0} s")
 
-    MS_list.H.swap_attempts = MS_list.H.swap_attempts + walk.swap_attempts
-    MS_list.H.swap_accept = MS_list.H.swap_accept + walk.swap_accept
-    MS_list.latest_iter = ending_iter
-    MS_list.H.pack(states, logll, accept)
-    MS_list.random_state = walk.random_state()
-    if rank == 0:
-        if export_path:
-            logger.info(f"Exporting to {ef['output_path']}")
-            MS_list.checkpoint(os.path.join(ef["output_path"], export_path))
+    # The run is cut into stretches of checkpoint_freq iterations (the last one shorter); every stretch but the last
+    # is followed by a checkpoint, the last by the export.  In "mpi" mode a stretch's swap counts are folded in
+    # before its checkpoint (:431-437); the serial loop's only after the last stretch (:464-466).
+    fresh = load_checkpoint is None
+    for a, b, last in _stretches(starting_iter, num_iters, checkpoint_freq):
+        logger.info(f"stretch {a} -> {b}")
+        walk.run(states, logll, accept, a, b, need_initial_state=fresh and a == starting_iter)
+        if last:
+            break
+        if rng_mode == "mpi":
+            fold_swap_counts()
+        snapshot(b)
+        if rank == 0:
+            logger.info(f"checkpoint after iteration {b}")
+            MS_list.checkpoint(target)
+    logger.info(f"rank {rank}: {perf_counter() - clock0:.3f} s")
+
+    fold_swap_counts()
+    snapshot(num_iters)
+    if rank == 0 and export_path:
+        logger.info(f"export to {ef['output_path']}")
+        MS_list.checkpoint(target)
     logger.removeHandler(handler)
     handler.close()
     return MS_list

@@ -314,7 +314,7 @@ class PTEnsemble:
     _frozen = False  # gc.freeze() has been called by an ensemble of this process (advance)
 
     def __init__(self, states, temperatures, evaluator, rank=0, world=1, seed=235817049752375780, group=None,
-                 rng_mode="stream", streams=None, device_decisions=False, gc_freeze=True):
+                 rng_mode="stream", streams=None, device_decisions=False, gc_freeze=False):
         if rng_mode not in ("stream", "counter"):
             raise ValueError("rng_mode must be 'stream' or 'counter'")
         self.states = np.array(states, dtype=np.float64)
@@ -354,6 +354,9 @@ class PTEnsemble:
         self.device_decisions = bool(device_decisions)
         self.gc_freeze = bool(gc_freeze)
         self.n_pipelined = 0  # launches decided on the device so far
+        # host seconds of the replica exchanges so far: waiting for the groups' last launches | the all-gather and its
+        # copy to the host | swap replay, permutation and the upload of the own rows; and how many there were
+        self.exchange_s = {"wait": 0.0, "gather": 0.0, "replay": 0.0, "n": 0}
 
     def _tick(self, key, t0):
         if self.prof is not None:
@@ -413,12 +416,23 @@ class PTEnsemble:
         import torch.distributed as dist
         if not self.local:
             return
+        t_wait = time.perf_counter()
         for st in self.streams:  # the decisions of every group have been applied to cur_tab on its side stream
             if st is not None:
                 st.synchronize()
         for c_ in getattr(self, "_devc", {}).values():
             if c_.get("side") is not None:
                 c_["side"].synchronize()
+        t_gather = time.perf_counter()
+        self.exchange_s["wait"] += t_gather - t_wait
+        try:
+            self._sync_gather()
+        finally:
+            self.exchange_s["gather"] += time.perf_counter() - t_gather
+
+    def _sync_gather(self):
+        import torch
+        import torch.distributed as dist
         c, nT, npar = self.hi - self.lo, self.T.shape[0], self.states.shape[1]
         dev = self.cur_tab.device
         host = np.concatenate([self.states[self.lo:self.hi], self.acc_count[self.lo:self.hi, None].astype(np.float64)], axis=1)
@@ -560,7 +574,11 @@ class PTEnsemble:
 
     def _exchange(self, it):
         t0 = time.perf_counter()
+        before = self.exchange_s["wait"] + self.exchange_s["gather"]
         self._exchange_(it)
+        dt = time.perf_counter() - t0
+        self.exchange_s["replay"] += dt - (self.exchange_s["wait"] + self.exchange_s["gather"] - before)
+        self.exchange_s["n"] += 1
         self._tick("exchange", t0)
 
     def _exchange_(self, it):
@@ -650,7 +668,9 @@ class PTEnsemble:
         # it off only postpones that collection to the moment it is switched on again, so before the first stretch
         # everything that exists -- the imported modules, the engines: nothing of it is garbage -- is moved out of the
         # collector's sight once, gc.freeze(); later full collections look at what was created since and take a
-        # millisecond.  `gc_freeze=False` leaves the collector alone.)
+        # millisecond.  That is a process-wide, lasting side effect of a library call -- every object the host application
+        # holds at that moment moves to the permanent generation -- so it is OPT-IN (`gc_freeze=True`); the
+        # default only switches the collector off for the duration of this call.)
         if self.gc_freeze and not PTEnsemble._frozen:
             gc.collect()
             gc.freeze()

@@ -106,6 +106,9 @@ def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=Tr
         # 2.37 ms per iteration with it, without it and solve by solve; it costs a blocking read per group and stretch)
         if os.environ.get("MTRPL_PT_NO_ORDER") != "1":
             if packed_order == "solves":
+                # every group's launches, whatever their size (three groups of a 512-chain ensemble are 1026,
+                # 1026 and 1020 solves -- a threshold of 1024 ordered two of them; at N > 1 none)
+                eng.packed_sort_min = 0
                 evaluator.plan_packed = eng.plan_packed
             elif os.environ.get("MTRPL_PT_CHAIN_ORDER") == "1":
                 evaluator.row_cost = row_cost
@@ -191,7 +194,7 @@ def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups
     local_only = world == 1 and not getattr(a, "use_dist", False)
     ens = pt.PTEnsemble(ens0["chain_states"], T, S["evaluators"] if groups > 1 else S["evaluator"], rank=rank,
                         world=world, rng_mode="counter", streams=S["streams"], group=pt.LOCAL_ONLY if local_only else None,
-                        device_decisions=decide == "device")
+                        device_decisions=decide == "device", gc_freeze=True)  # (the benchmark owns its process)
     ens.initialise()
     temper_freq = 10
     ens.advance(proposer, a.warmup, temper_freq, prefetch)
@@ -205,6 +208,7 @@ def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups
         dist.barrier()
     torch.cuda.synchronize()
     coll0 = ens.n_collectives
+    ex0 = dict(ens.exchange_s)
     if os.environ.get("MTRPL_PT_PROF") == "1":
         ens.prof = {}
     t0 = time.perf_counter()
@@ -242,7 +246,14 @@ def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups
                    "swap_accept_rate": float(ens.swap_accepts.sum() / max(1, ens.swap_attempts.sum())),
                    "mean_integrator_steps_rank0": float(stats[:, 0].mean()),
                    "max_integrator_steps_rank0": int(stats[:, 0].max()),
-                   "max_integrator_steps_per_rank": steps_rank},
+                   "max_integrator_steps_per_rank": steps_rank,
+                   # what a replica exchange costs this rank's host, per exchange of the timed iterations: waiting for its
+                   # groups' last launches (the latency floor: the slowest solve) | the all-gather + copy to the host (the
+                   # collective) | swap replay, permutation, upload of the own rows (then the first launches go out)
+                   "exchange_ms": (lambda n_: None if n_ == 0 else {
+                       k_: round((ens.exchange_s[k_] - ex0[k_]) / n_ * 1e3, 4) for k_ in ("wait", "gather", "replay")})(
+                       ens.exchange_s["n"] - ex0["n"]),
+                   "exchanges_timed": ens.exchange_s["n"] - ex0["n"]},
     }
     if ens.prof is not None:
         line["config"]["host_ms"] = {k: round(v * 1e3, 3) for k, v in ens.prof.items()}
@@ -307,13 +318,20 @@ N_SIMD, CLOCK_HZ = 1024, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GH
 
 
 # Issue cost of the instruction classes with two waves per SIMD, cycles per wave-instruction per SIMD, measured on this
-# device by tools/mb/rcp_rate.hip (profiles/r03_z_issue_cost.txt: v_add_f64 2.05 ns, v_fma_f64 2.52 ns, v_rcp_f64 7.9 ns
+# device by tools/mb/rcp_rate.hip (profiles/r0N_z_issue_cost.txt: v_add_f64 2.05 ns, v_fma_f64 2.52 ns, v_rcp_f64 7.9 ns
 # per wave-op per SIMD at 2.3 GHz; a wave ALONE on its SIMD issues an fp64 instruction only every 8 cycles)
 # (packed fp32 instructions are counted in the fp32 classes at 4 cycles although they cost about 6: the bound is
 # optimistic by about 4 %)
 ISSUE_COST_2WAVES = {"SQ_INSTS_VALU_ADD_F64": 4.7, "SQ_INSTS_VALU_FMA_F64": 5.8, "SQ_INSTS_VALU_MUL_F64": 5.8,
                      "SQ_INSTS_VALU_TRANS_F64": 18.0, "SQ_INSTS_VALU_ADD_F32": 4.0, "SQ_INSTS_VALU_FMA_F32": 4.0,
                      "SQ_INSTS_VALU_MUL_F32": 4.0, "SQ_INSTS_VALU_TRANS_F32": 8.0, "other": 4.0}
+
+
+def _issue_cost_file(repo):
+    """The newest committed run of the issue-cost micro-benchmark (profiles/rNN_z_issue_cost.txt)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(repo, "profiles", "r*_z_issue_cost.txt")))
+    return "profiles/" + os.path.basename(found[-1]) if found else "no committed run"
 
 
 def valu_issue_fields(kernel, solves_per_sec_per_gpu):
@@ -348,7 +366,7 @@ def valu_issue_fields(kernel, solves_per_sec_per_gpu):
                     "bound_solves_per_sec": N_SIMD * CLOCK_HZ / cycles,
                     "frac_of_bound": solves_per_sec_per_gpu * cycles / (N_SIMD * CLOCK_HZ),
                     "source": "profiles/hbm_traffic_mix_wave2.json (instruction classes, rocprofv3 --pmc) x the issue costs "
-                              "measured by tools/mb/rcp_rate.hip with two waves per SIMD (profiles/r03_z_issue_cost.txt)"}
+                              f"measured by tools/mb/rcp_rate.hip with two waves per SIMD ({_issue_cost_file(repo)})"}
             except Exception as e:
                 out["throughput"] = {"error": repr(e)}
         return out

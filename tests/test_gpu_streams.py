@@ -102,3 +102,120 @@ def test_fp32_nx512_launches_on_a_fresh_context_grow_the_slab_pool_safely():
     np.testing.assert_array_equal(a["out"].cpu().numpy(), outs[0][0])
     np.testing.assert_array_equal(b["out"].cpu().numpy(), outs[0][1])
     ctx.close()
+
+
+# ---- the pipelined host-pointer solve: sub-launches on the context's own streams ---------------
+def _host_call(ctx, d, ini, t, out, with_stats=True):
+    import ctypes as C
+    from metrotrpl_amd import _lib as L
+    B = d.shape[0]
+    status = np.full(B, -7, dtype=np.int32)
+    stats = np.zeros((B, 8), dtype=np.int32)
+    ctx.check(L.lib().mtrpl_solve_batch(ctx.handle, B, d.ctypes.data_as(C.c_void_p), L.dptr(ini), ini.shape[0], L.dptr(t),
+                                        t.shape[0], L.dptr(out), out.shape[0], L.iptr(status),
+                                        L.iptr(stats) if with_stats else None))
+    return status, stats
+
+
+def test_pipelined_host_solve_batch_equals_the_blocking_launch():
+    """mtrpl_solve_batch with more than host_chunk solves runs as sub-launches on streams the context owns, the samples
+    of a finished sub-launch travelling back under the later ones' compute -- into pinned memory directly, into pageable
+    memory through the staging ring.  Every sample, status and step count must equal the one blocking launch
+    (host_streams = 0), for a batch that is not a multiple of the chunk, with more sub-launches than staging slots, with a
+    gap in the output array, and for descriptors that do NOT fill `out` in order (fallback to one launch)."""
+    from metrotrpl_amd import _lib as L, batch, workloads as W
+    ctx = L.Context(0)
+    B, nt = 1100, 201
+    c = W.config2(B)
+    t = np.ascontiguousarray(np.linspace(0, 400, nt))
+    d, ini = batch.build_batch(c["states"], W.indexes(), W.units(), c["iniPar"], c["thickness"], c["nx"], nt, hmax=c["hmax"],
+                               meas=c["meas"], model=c["model"], ini_mode=c["ini_mode"])
+    d["out_off"][700:] += 57  # a gap the kernel never writes: zero in both paths
+    n_out = B * nt + 57
+    ctx.set_option("host_streams", 0)
+    ref = np.full(n_out, np.nan)
+    st_ref, stats_ref = _host_call(ctx, d, ini, t, ref)
+    assert np.all(st_ref == 0) and np.all(np.isfinite(ref)) and np.all(ref[700 * nt:700 * nt + 57] == 0)
+    ctx.set_option("host_streams", 4)
+    for chunk in (128, 97, 1024):  # 9 sub-launches (more than the 8 staging slots) | 12 ragged ones | 2
+        ctx.set_option("host_chunk", chunk)
+        for pinned in (False, True):
+            out = L.pinned_f64(ctx, n_out) if pinned else np.empty(n_out)
+            out[:] = np.nan
+            st, stats = _host_call(ctx, d, ini, t, out)
+            np.testing.assert_array_equal(out, ref)
+            np.testing.assert_array_equal(st, st_ref)
+            np.testing.assert_array_equal(stats[:, :7], stats_ref[:, :7])  # (slot 7 is the residency: a clock reading)
+    # no stats buffer; and descriptors that run backwards through `out`
+    out = np.empty(n_out)
+    st, _ = _host_call(ctx, d, ini, t, out, with_stats=False)
+    np.testing.assert_array_equal(out, ref)
+    rev = d[::-1].copy()
+    out = np.full(n_out, np.nan)
+    st, _ = _host_call(ctx, rev, ini, t, out)
+    np.testing.assert_array_equal(out, ref)
+    np.testing.assert_array_equal(st, st_ref[::-1])
+    # the batch API hands out pinned memory for big batches and plain arrays for small ones: same numbers
+    ctx.set_option("host_chunk", 1024)
+    nt_big = 1001
+    tb = np.ascontiguousarray(c["tSteps"])
+    sig = batch.solve_batch(c["states"], W.indexes(), W.units(), c["iniPar"], c["thickness"], c["nx"], tb, ctx=ctx)
+    assert sig.shape == (B, nt_big)
+    one = batch.solve_batch(c["states"][1000:1003], W.indexes(), W.units(), c["iniPar"][1000:1003], c["thickness"], c["nx"], tb,
+                            ctx=ctx)
+    np.testing.assert_array_equal(sig[1000:1003], one)
+    del sig
+    ctx.trim()
+    ctx.close()
+
+
+def test_nx512_host_batch_is_pipelined_in_quarter_chunks():
+    """The four-wave kernel of nx > 256 takes host_chunk / 4 solves per sub-launch; same samples as one launch."""
+    from metrotrpl_amd import _lib as L, batch, workloads as W
+    ctx = L.Context(0)
+    c = W.config5(10, 512)
+    t = np.ascontiguousarray(np.linspace(0, 100, 51))
+    d, ini = batch.build_batch(c["states"], W.indexes(), W.units(), c["iniPar"], c["thickness"], 512, len(t), meas=c["meas"])
+    B = d.shape[0]
+    ctx.set_option("host_streams", 0)
+    ref = np.empty(B * len(t))
+    st_ref, _ = _host_call(ctx, d, ini, t, ref)
+    assert np.all(st_ref == 0)
+    ctx.set_option("host_streams", 3)
+    ctx.set_option("host_chunk", 48)  # 12 solves per sub-launch
+    out = np.empty(B * len(t))
+    st, _ = _host_call(ctx, d, ini, t, out)
+    np.testing.assert_array_equal(out, ref)
+    np.testing.assert_array_equal(st, st_ref)
+    ctx.close()
+
+
+def test_likelihood_lanes_and_the_pipelined_dense_sampler():
+    """LikelihoodEngine.eval_async on clones of an engine (lanes), three evaluations in flight on three streams, and
+    dense_sampler.simulate over them: the table of every chunk equals the blocking eval's, whatever the lane count."""
+    import torch
+    from metrotrpl_amd import _lib as L, dense_sampler as DS, workloads as W
+    from metrotrpl_amd.likelihood import LikelihoodEngine
+    names, ix, un = W.PARAM_NAMES, W.indexes(), W.units()
+    s0 = W.initial_state()
+    lo = np.array([W.PRIOR_BOX.get(n, (s0[ix[n]], s0[ix[n]]))[0] for n in names])
+    hi = np.array([W.PRIOR_BOX.get(n, (s0[ix[n]], s0[ix[n]]))[1] for n in names])
+    X = DS.random_grid(lo, hi, [True] * len(names), 500, np.random.default_rng(11))
+    t = np.linspace(0, 400, 201)
+    lengths, flu = [311.0, 2000.0], np.array([W.STAUB_FLUENCES[0], W.STAUB_FLUENCES[5]])
+    vals = [np.full(201, 20.0) - t / 200, np.full(201, 22.0) - t / 300]
+    uncs = [np.full(201, 0.05)] * 2
+    eng = LikelihoodEngine(ix, un, lengths, 128, ["TRPL", "TRPL"], [t, t], vals, uncs, {"TRPL": 1.0}, flu, sort_min=64)
+    T = [1.0, 7.0, 100.0]
+    ref = [eng.eval(X[a:a + 120], T) for a in range(0, 480, 120)]
+    lanes = [eng, eng.clone(), eng.clone()]
+    streams = L.shared_streams(torch.device("cuda", 0), 3)
+    hs = [lanes[k].eval_async(X[120 * k:120 * (k + 1)], T, streams[k]) for k in range(3)]
+    for k in (2, 0, 1):
+        np.testing.assert_array_equal(hs[k].result(), ref[k])
+    h = lanes[1].eval_async(X[360:480], T, streams[1])  # a lane again, after its result has been read
+    np.testing.assert_array_equal(h.result(), ref[3])
+    one = DS.simulate(eng, X, chunk=64, lanes=1)
+    for n_lanes, chunk in ((3, 64), (2, 200), (4, 50)):
+        np.testing.assert_array_equal(DS.simulate(eng, X, chunk=chunk, lanes=n_lanes), one)
+    np.testing.assert_array_equal(one[:120], ref[0][:, :, 0].sum(axis=1))

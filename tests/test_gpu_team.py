@@ -256,22 +256,15 @@ def test_mixed_trpl_trts_likelihood_at_nx512(team):
     table = eng.eval(team["mixed_state"][None, :], team["mixed_T"])[0]
     ref = team["mixed_table"]
     assert ref.shape == table.shape == (2, 4) and np.all(np.isfinite(ref)) and np.all(ref < 0)
-    # The data of this fixture are the traces of a NEIGHBOURING state: err = log10(sig) - vals is small (0.02 ... 0.06),
-    # so a relative error eps of the simulated signal moves ll = -sum err^2 / (sigma^2 T + 2 u^2) by 2 eps / (ln 10 |err|)
-    # relatively -- about 20 eps.  The gate is therefore the SIGNAL gate of SURVEY 8d (1e-6, here held at 2e-7) carried
-    # through to first order, sample by sample: |d ll| <= sum 2 |err_i| (eps / ln 10) / (sigma^2 T + 2 u_i^2).  (Round 3
-    # asked for 1e-6 on ll itself, i.e. 5e-8 on the signal, tighter than the oracle of this fixture -- LSODA at
-    # rtol 1e-10 -- is converged.)
-    nt = len(t)
-    sig = eng.d_sig.cpu().numpy().reshape(2, nt)
-    eps = 2e-7
-    for m in range(2):
-        err = np.log10(sig[m]) - team["mixed_vals"][m]
-        sg2 = float(team["mixed_sigma"][m]) ** 2
-        bound = np.array([np.sum(2 * np.abs(err) * (eps / np.log(10)) / (sg2 * T_ + 2 * team["mixed_uncs"][m] ** 2))
-                          for T_ in team["mixed_T"]])
-        assert np.all(np.abs(table[m] - ref[m]) <= bound + 1e-12), (m, np.abs(table[m] - ref[m]) / bound)
-        assert np.all(bound < 1e-4 * np.abs(ref[m]))  # the bound is a tight one: a few 1e-6 (TRPL) / 1e-5 (TRTS) of ll
+    # SURVEY 8d's log-likelihood gate, literally: |d logll| <= 1e-6 |logll| at every temperature, against the CONVERGED
+    # oracle (RTOL 1e-12, vector ATOL: its own uncertainty on this table is 6e-12 / 4e-9, stored as mixed_table_u).  The
+    # data of this fixture are the traces of a NEIGHBOURING state, so err = log10(sig) - vals is small (0.02 ... 0.06)
+    # and a relative error eps of the simulated signal moves ll by about 20 eps: the gate asks 5e-8 of the signal over
+    # the 1.5 decades these traces span.  (Round 4 had widened it to a first-order bound because the fixture's oracle --
+    # LSODA at 1e-10 -- was not converged; VERDICT r4 weak 1b: fix the fixture, not the gate.)
+    rel = np.abs(table - ref) / np.abs(ref)
+    print("mixed TRPL + TRTS at nx = 512: |d ll| / |ll| =", rel.round(10).tolist())
+    assert np.all(rel <= 1e-6 + team["mixed_table_u"]), rel
 
 
 def test_spike_linear_solver_against_dense_solves():
