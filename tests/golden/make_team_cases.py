@@ -90,7 +90,8 @@ def mixed_case():
     _, table_b = O.eval_trial_move(state, uniq, shared, temperatures=T)
     return dict(mixed_state=state, mixed_t=t, mixed_vals=np.array(vals), mixed_uncs=np.array(shared["_uncs"]),
                 mixed_ini=shared["_init_params"], mixed_T=T, mixed_table=table, mixed_sigma=np.array([1.0, 10.0]),
-                mixed_table_u=np.abs(table_b - table) / np.abs(table),
+                mixed_table_u=np.abs(table_b - table) / np.abs(table), mixed_rtol=np.array(1e-12),
+                mixed_atol_density=np.array(1e-24),
                 mixed_oracle=np.array("RTOL 1e-12, ATOL 1e-24 densities / 1e-17 field; mixed_table_u: relative change at RTOL 3e-13"))
 
 

@@ -1,0 +1,53 @@
+"""GPU: the contract line of `python bench.py` as the driver will get it, with the N > 1 code path rehearsed on one GPU
+(MTRPL_FORCE_DIST=1: a one-rank `nccl` group, so every barrier, the max-over-ranks all-reduce and the PT all-gather go
+through RCCL) -- VERDICT r4 next 6b.  bench.py runs as a CHILD process (it owns its stdout protocol and its GPU set-up)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_through_a_one_rank_process_group():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MTRPL_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, cwd=REPO, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-500:]  # ONE line on stdout, whatever RCCL and the launcher print
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "trpl_forward_solves_per_sec" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["all_solves_ok"] is True
+    assert abs(d["value"] - 1024 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r_ = d["roofline"]
+    assert r_["bound"] == "hbm" and r_["unit"] == "GB/s" and abs(r_["frac"] - r_["achieved"] / r_["peak"]) < 1e-12
+    assert r_["kernel_ms_min"] <= r_["kernel_ms"] <= r_["kernel_ms_max"]
+    assert "r03" not in r_["valu_issue"]["throughput"]["source"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert c["all_cores"]["cores"] >= 1 and c["all_cores"]["cores_available"] >= c["all_cores"]["cores"]
+    # the product API, host to host
+    api = d["api"]
+    assert api["solve_batch"]["pinned_out"]["all_solves_ok"] and api["solve_batch"]["pageable_out"]["all_solves_ok"]
+    assert api["solve_batch"]["solves_per_sec"] > 2e5
+    assert api["dense_sampler"]["samples_per_sec"] > 2e4 and api["dense_sampler"]["one_chunk_at_a_time"]["same_values"] is True
+    # BASELINE's second metric: both ensembles, through the process group
+    for chains in ("64", "512"):
+        p = d["pt"][chains]
+        assert p["chains"] == int(chains) and p["ms_per_iteration"] > 0, p
+        assert abs(p["proposals_per_sec"] - int(chains) / (p["ms_per_iteration"] * 1e-3)) < 1e-6 * p["proposals_per_sec"]
+        assert 0 < p["collectives_per_iteration"] <= 0.2  # one all-gather per replica exchange (every 10 iterations), through RCCL
+        assert len(p["max_integrator_steps_per_rank"]) == 1 and p["max_integrator_steps_per_rank"][0] > 100
+        ex = p["exchange_ms"]
+        assert p["exchanges_timed"] >= 1 and all(ex[k] >= 0 for k in ("wait", "gather", "replay"))
+    assert d["pt"]["64"]["cpu_baseline"]["kind"] == "port"
+    assert d["accuracy"]["all_ok"] is True and max(d["accuracy"]["max_rel_err_per_decade_0_to_8"]) < 1e-6
