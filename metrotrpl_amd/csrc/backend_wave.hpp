@@ -35,6 +35,7 @@ struct WaveBackendT {
     using real = double;
     static constexpr int R = 2, V = 6;
     static constexpr bool TRAPS = false;
+    static constexpr bool kFieldInNorms = false;  // the field components in the controller's norms (solve_core.hpp)
     static constexpr bool kParksSamples = false;  // out_sample() parks, out_flush() emits
 
     Par p;

@@ -69,6 +69,13 @@ __device__ inline T signal_density(const ParT<T> &p, int meas, T N, T P, T Ntrap
     const T dN = N - p.n0;
     return (meas == MTRPL_MEAS_TRPL) ? p.ks * (N * P - p.n0p0) : (T)kQC * (p.mun * dN + p.mup * (dN + Ntrap));
 }
+// the std model (no trapped density: dN + 0 is dN, written out so that no addition of a zero is left in the sample loop)
+template <class T>
+__device__ inline T signal_density(const ParT<T> &p, int meas, T N, T P)
+{
+    const T dN = N - p.n0;
+    return (meas == MTRPL_MEAS_TRPL) ? p.ks * (N * P - p.n0p0) : (T)kQC * (p.mun * dN + p.mup * dN);
+}
 // ... and literally as the reference writes it: for the zeroed state behind an early stop (:168), which is not a
 // state of the model
 template <class T>

@@ -34,6 +34,8 @@
 // hardware sqrt / rcp / log / exp tripled their number.  Everything order-dependent comes from one 128-byte row
 // of a table in constant memory (scalar loads), not from a switch over the order.
 #pragma once
+#include <type_traits>
+
 #include "model_physics.hpp"
 
 // Diagnostic build only (-DMTRPL_STAMPS): s_memtime per phase; the real kernel has no stamps.
@@ -108,7 +110,7 @@ struct SolveTuning {
 // The shipped settings as compile-time constants: a kernel instantiated on this type instead of on the
 // run-time struct keeps none of them in (spilled) scalar registers.  Single source of the defaults.
 struct DefaultTune {
-    static constexpr double rtol_scale = 0.1, rtol_cap = 3e-9, rtol_floor = 3e-10, rtol_min = 3e-11, rtol_force = 0.0;
+    static constexpr double rtol_scale = 0.1, rtol_cap = 2.4e-9, rtol_floor = 3e-10, rtol_min = 3e-11, rtol_force = 0.0;
     static constexpr double atol_rel = 1e-4, atol_rel_np = 1e-9;
     static constexpr int max_steps = 2000000;
     static constexpr double newton_tol = 0.1;
@@ -380,6 +382,11 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
     // (TRPL only: the photoconductivity weighs dP directly, and its p99 census error doubles with a looser field)
     const real rtol_E = rtol * ((meas == MTRPL_MEAS_TRPL) ? (real)tune.e_weight : (real)1);
     auto is_E = [](int v) { return v >= 2 * R && v < 3 * R; };
+    // Backends may leave the field components out of the controller's norms (BK::kFieldInNorms = false): E is slaved to the
+    // charge (Gauss's law is a linear invariant of the system: dE_i/dt = -Lam (Jn_i + Jp_i) is its time derivative), its
+    // correction follows the densities' through the back-substitution, and its weight is the loosest of the three.
+    constexpr bool kNormE = BK::kFieldInNorms;
+    auto in_norm = [&](int v) { return kNormE || !is_E(v); };
     auto rtol_of = [&](int v) { return is_E(v) ? rtol_E : rtol; };
     auto atol_of = [&](int v) { return is_E(v) ? atol_E : atol; };
     // the same as fp32 values: what the weights 1/(atol + rtol |y|) are built from.  Densities (1e-4 ... 1e-22 nm^-3)
@@ -403,7 +410,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         real s = (real)0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const real v = TRAPS ? signal_density(p, meas, nn[r], pp[r], tr[r]) : signal_density(p, meas, nn[r], pp[r], (real)0);
+            const real v = TRAPS ? signal_density(p, meas, nn[r], pp[r], tr[r]) : signal_density(p, meas, nn[r], pp[r]);
             s += (bk.node(r) < L) ? v : (real)0;
         }
         return s;
@@ -521,7 +528,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         float isc[V];
 #pragma unroll
         for (int v = 0; v < V; ++v)
-            isc[v] = __builtin_amdgcn_rcpf(fmaf(is_E(v) ? rtol_E_f : rtol_f, fabsf((float)z[0][v]), is_E(v) ? atol_E_f : atol_f));
+            isc[v] = in_norm(v) ? __builtin_amdgcn_rcpf(fmaf(is_E(v) ? rtol_E_f : rtol_f, fabsf((float)z[0][v]), is_E(v) ? atol_E_f : atol_f)) : 0.0f;
         // per-node step: zero on the padded slots (node >= L), whose right-hand side is never looked at
         real hv[R];
 #pragma unroll
@@ -573,6 +580,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
                     acor[v] += dxv[v];
+                    if (!in_norm(v)) { acf[v] = 0.0f; continue; }
                     const float wv = (float)dxv[v] * isc[v];
                     acf[v] = (float)acor[v];
                     const float av = acf[v] * isc[v];
@@ -597,7 +605,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                     const float elK = (float)nq.elK;
                     // (a switch with one loop per case: a select chain over z[1..5][v] is turned into a load with a
                     // run-time row index, and the whole history then lives in memory)
-#define MTRPL_DDN_ROW(J) for (int v = 0; v < V; ++v) { const float q_ = fmaf(elK, acf[v], (float)z[J][v]) * isc[v]; s4[2] = fmaf(q_, q_, s4[2]); }
+#define MTRPL_DDN_ROW(J) for (int v = 0; v < V; ++v) { if (!in_norm(v)) continue; const float q_ = fmaf(elK, acf[v], (float)z[J][v]) * isc[v]; s4[2] = fmaf(q_, q_, s4[2]); }
                     switch (order) {
                         case 1: MTRPL_DDN_ROW(1) break;
                         case 2: MTRPL_DDN_ROW(2) break;
@@ -608,6 +616,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
 #undef MTRPL_DDN_ROW
 #pragma unroll
                     for (int v = 0; v < V; ++v) {
+                        if (!in_norm(v)) continue;
                         const float a_ = (acf[v] - acp[v]) * isc[v];
                         s4[3] = fmaf(a_, a_, s4[3]);
                     }
@@ -717,31 +726,45 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             // dense output (Taylor polynomial of the Nordsieck array), forward_solver.py:167: only N and P enter the signal
             if (!(tq_next > t * (real)(1.0 + 1e-15))) {
                 const real ih = frcp(h);
-                do {
-                    const real s_ = (tq_next - t) * ih;
-                    real nn[R], pp[R], tr[R];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        nn[r] = z[5][r];
-                        pp[r] = z[5][R + r];
-                        tr[r] = TRAPS ? z[5][(TRAPS ? 3 : 0) * R + r] : (real)0;
-                    }
-#pragma unroll
-                    for (int j = 4; j >= 0; --j)
+                // The kind of signal is wave-uniform and fixed for the solve: the sample loop exists once per kind, so that
+                // no branch stands between the Horner chains of a sample (written with the kind tested per node the
+                // compiler kept four branches per sample, and the four five-deep FMA chains ran one after the other).
+                auto samples = [&](auto kind_) {
+                    constexpr int KIND = decltype(kind_)::value;
+                    do {
+                        const real s_ = (tq_next - t) * ih;
+                        real nn[R], pp[R], tr[R];
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
-                            nn[r] = nn[r] * s_ + z[j][r];
-                            pp[r] = pp[r] * s_ + z[j][R + r];
-                            if (TRAPS) tr[r] = tr[r] * s_ + z[j][(TRAPS ? 3 : 0) * R + r];
+                            nn[r] = z[5][r];
+                            pp[r] = z[5][R + r];
+                            tr[r] = TRAPS ? z[5][(TRAPS ? 3 : 0) * R + r] : (real)0;
                         }
-                    bk.out_sample(io, sig_partial(nn, pp, tr));
-                    io++;
-                    if (io - io0 >= 64) {
-                        io0 = io;
-                        tsv = (io0 + lane64 < nt) ? ts[io0 + lane64] : 1e300;
-                    }
-                    tq_next = (io < nt) ? (real)lane_value(tsv, io - io0) : big<real>();
-                } while (!(tq_next > t * (real)(1.0 + 1e-15)));
+#pragma unroll
+                        for (int j = 4; j >= 0; --j)
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                nn[r] = nn[r] * s_ + z[j][r];
+                                if (KIND == MTRPL_MEAS_TRPL) pp[r] = pp[r] * s_ + z[j][R + r];  // (the photoconductivity is emitted from N alone)
+                                if (TRAPS) tr[r] = tr[r] * s_ + z[j][(TRAPS ? 3 : 0) * R + r];
+                            }
+                        real sp = (real)0;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const real v = TRAPS ? signal_density(p, KIND, nn[r], pp[r], tr[r]) : signal_density(p, KIND, nn[r], pp[r]);
+                            sp += (bk.node(r) < L) ? v : (real)0;
+                        }
+                        bk.out_sample(io, sp);
+                        io++;
+                        if (io - io0 >= 64) {
+                            io0 = io;
+                            tsv = (io0 + lane64 < nt) ? ts[io0 + lane64] : 1e300;
+                        }
+                        tq_next = (io < nt) ? (real)lane_value(tsv, io - io0) : big<real>();
+                    } while (!(tq_next > t * (real)(1.0 + 1e-15)));
+                };
+                if (meas == MTRPL_MEAS_TRPL) samples(std::integral_constant<int, MTRPL_MEAS_TRPL>{});
+                else samples(std::integral_constant<int, MTRPL_MEAS_TRTS>{});
                 if constexpr (BK::kParksSamples) bk.out_flush();  // (backends that park the samples of a step: one exchange for all of them)
             }
             MTRPL_STAMP(ph_dense);

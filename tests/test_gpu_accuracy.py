@@ -9,7 +9,13 @@ trace and decade (`u_oracle`: the same solves at a 100x smaller density ATOL and
 5e-9 through decade 8, 2.6e-8 / 1.9e-7 / 1.3e-6 in decades 9 / 10 / 11).  From decade 9 on the signal is the
 difference N P - n0 p0 of nearly equal numbers, nothing measured reaches down there and the integrator's local
 tolerance is relaxed again (options far_frac / far_factor): the bounds widen and are regression guards, not
-accuracy claims.  DESIGN.md section 2 prints the measured table."""
+accuracy claims.  DESIGN.md section 2 prints the measured table.
+
+The MEDIAN bounds are regression guards too, ten to a hundred times inside the contract.  Round 5 took the field components
+out of the controller's norms (they were setting the step size of most steps without being part of any signal: 9 % fewer
+steps) and tightened the internal rtol from 3e-9 to 2.4e-9 in exchange: the maxima came out as before or better (config 2
+decade 8: 6.2e-7 against 6.5e-7), the medians of decades 1 and 2 moved from 7e-9 / 1.7e-8 to 1.3e-8 / 2.4e-8 -- the error
+budget is spent more evenly -- and their guards from 1e-8 / 3e-8 to 2e-8 / 4e-8."""
 import os
 
 import numpy as np
@@ -20,7 +26,7 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 
 #          decade: 0     1     2     3     4     5     6     7     8     9     10
 MAX_BOUND = [1e-6, 1e-6, 1e-6, 1e-6, 1e-6, 1e-6, 1e-6, 1e-6, 1e-6, 2e-5, 2e-4]
-MEDIAN_BOUND = [1e-8, 1e-8, 3e-8, 1e-7, 1e-7, 2e-7, 3e-7, 5e-7, 8e-7, 1.5e-6, 3e-6]
+MEDIAN_BOUND = [1e-8, 2e-8, 4e-8, 1e-7, 1e-7, 2e-7, 3e-7, 5e-7, 8e-7, 1.5e-6, 3e-6]
 
 
 def per_decade(sig, ref, u_oracle):
