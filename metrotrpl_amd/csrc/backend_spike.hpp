@@ -306,7 +306,7 @@ struct SpikeBackendT {
         done();
         M2 Lm[R], Rm[R], A[R], B[R], C[R];
         const double cL = c * p.Lam;
-        const double dnx = p.DnT * p.idx, dpx = p.DpT * p.idx;
+        const double dnx = p.dnx, dpx = p.dpx;
         const double Nlw = pinned(from_prev(y[R - 1])), Plw = pinned(from_prev(y[2 * R - 1]));
         const double Nl = (lane == 0) ? plN : Nlw;
         const double Pl = (lane == 0) ? plP : Plw;

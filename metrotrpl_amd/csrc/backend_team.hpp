@@ -253,7 +253,7 @@ struct TeamBackend {
         for (int v = 0; v < V; ++v) y[v] = pinned(y_in[v]);  // keep the Jacobian inside the branch it is called from
         const real cL = c * p.Lam;
         cd = c * p.idx;
-        const real dnx = p.DnT * p.idx, dpx = p.DpT * p.idx;
+        const real dnx = p.dnx, dpx = p.dpx;
         row_t o1[1], in1[1] = {d2(y[1], y[3])};
         xget<1>(in1, (tid + T - 1) & (T - 1), o1);
         M2r Lm[2], Rm[2];

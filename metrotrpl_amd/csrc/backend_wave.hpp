@@ -111,6 +111,15 @@ struct WaveBackendT {
         double Jn[R + 1], Jp[R + 1];
         const double Nl = from_prev(y[R - 1]);
         const double Pl = from_prev(y[2 * R - 1]);
+        // The two surface terms S (N P - n0 p0) / (N + P) (:346-347) live in two different lanes -- the front's in lane 0
+        // (node 0), the back's in the lane of node L - 1, slot (L - 1) & 1 -- so ONE evaluation per lane serves both: each
+        // lane forms the term of the node it might own a surface of.  (Only a two-node grid has both in one lane.)
+        const bool back1 = ((L - 1) & 1) != 0;  // wave-uniform: the back surface sits in slot 1 of its lane
+        const bool s1 = back1 && lane != 0;
+        const double Ns = s1 ? y[1] : y[0], Ps = s1 ? y[R + 1] : y[R];
+        const double St = ((lane == 0) ? p.Sf : p.Sb) * (Ns * Ps - p.n0p0) * frcp1(Ns + Ps);
+        double Sbt = St;
+        if (__builtin_expect(L == 2, 0)) Sbt = p.Sb * (y[1] * y[R + 1] - p.n0p0) * frcp1(y[1] + y[R + 1]);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = lane * R + r;
@@ -120,9 +129,8 @@ struct WaveBackendT {
             double jn, jp;
             edge_flux(p, Nm, N, Pm, P, E, jn, jp);  // :356-359
             if (r == 0) {  // :346-351 (lane 0 only)
-                const double Sft = surface_term(p, p.Sf, N, P);
-                jn = (i == 0) ? Sft : jn;
-                jp = (i == 0) ? -Sft : jp;
+                jn = (i == 0) ? St : jn;
+                jp = (i == 0) ? -St : jp;
             }
             Jn[r] = jn;
             Jp[r] = jp;
@@ -136,7 +144,6 @@ struct WaveBackendT {
             const double NP = N * P - p.n0p0;
             double jnr = Jn[r + 1], jpr = Jp[r + 1];
             if (i == L - 1) {  // :347,:350,:352
-                const double Sbt = p.Sb * NP * frcp1(N + P);
                 jnr = -Sbt;
                 jpr = Sbt;
             }
@@ -155,7 +162,7 @@ struct WaveBackendT {
         for (int v = 0; v < V; ++v) y[v] = pinned(y_in[v]);  // keep the Jacobian inside the branch it is called from
         M2 Lm[R], Rm[R], A[R], B[R], C[R];
         const double cL = c * p.Lam;
-        const double dnx = p.DnT * p.idx, dpx = p.DpT * p.idx;
+        const double dnx = p.dnx, dpx = p.dpx;
         const double Nl = from_prev(y[R - 1]);
         const double Pl = from_prev(y[2 * R - 1]);
 #pragma unroll
