@@ -399,38 +399,39 @@ struct SpikeBackendT {
         M2 Wr = msel(lane == 63 && wave < W - 1, Ck, mzero<double>());
         Ak = msel(lane == 0, mzero<double>(), Ak);
         Ck = msel(lane == 63, mzero<double>(), Ck);
-        auto level = [&](int lv, const M2 &Bim, const M2 &Bip, const M2 &Akm, const M2 &Akp, const M2 &Ckm, const M2 &Ckp,
-                         const M2 &Vm, const M2 &Vp, const M2 &Wm, const M2 &Wp) {
-            const M2 al = mmul(Ak, Bim), ga = mmul(Ck, Bip);
+        // One PCR level, its ten neighbour blocks fetched in FIVE groups of two, each group requested only when the one
+        // before has been consumed: the source of a group's exchange is pinned behind the previous group's result (volatile
+        // asms keep their order), so the scheduler cannot hoist all ten exchanges -- 80 registers -- to the top of the
+        // level.  `xm` / `xp` fetch a block from the row below / above at this level's stride.
+        auto level = [&](int lv, auto &&xm, auto &&xp) {
+            const M2 Bi = minv(Bk);
+            const M2 al = mmul(Ak, xm(Bi)), ga = mmul(Ck, xp(Bi));
             if (lv < 5) {
                 static_cast<float4 *>(lds)[(PAL0 + lv) * 64 + lane] = float4{(float)al.a, (float)al.c, (float)al.b, (float)al.d};
                 static_cast<float4 *>(lds)[(PGA0 + lv) * 64 + lane] = float4{(float)ga.a, (float)ga.c, (float)ga.b, (float)ga.d};
             } else {
                 put(L5ROW, msel(lane < 32, ga, al));  // (al = 0 where lane < 32, ga = 0 where lane >= 32)
             }
-            Vr = msub(msub(Vr, mmul(al, Vm)), mmul(ga, Vp));
-            Wr = msub(msub(Wr, mmul(al, Wm)), mmul(ga, Wp));
-            Bk = msub(msub(Bk, mmul(al, Ckm)), mmul(ga, Akp));
-            Ak = mneg(mmul(al, Akm));
-            Ck = mneg(mmul(ga, Ckp));
+            const M2 alp = mpin(al), gap = mpin(ga);
+            const M2 Ak0 = mpin(Ak), Ck0 = mpin(Ck);
+            Bk = mpin(msub(msub(Bk, mmul(alp, xm(Ck0))), mmul(gap, xp(Ak0))));
+            const M2 Ak1 = mpin(Ak0), Ck1 = mpin(Ck0);
+            Ak = mpin(mneg(mmul(alp, xm(Ak1))));
+            Ck = mpin(mneg(mmul(gap, xp(Ck1))));
+            const M2 Vr0 = mpin(Vr);
+            Vr = mpin(msub(msub(Vr0, mmul(alp, xm(Vr0))), mmul(gap, xp(Vr0))));
+            const M2 Wr0 = mpin(Wr);
+            Wr = mpin(msub(msub(Wr0, mmul(alp, xm(Wr0))), mmul(gap, xp(Wr0))));
         };
-        {   // level 0: nearest neighbours by DPP wave shifts
-            const M2 Bi = minv(Bk);
-            level(0, mprev(Bi), mnext(Bi), mprev(Ak), mnext(Ak), mprev(Ck), mnext(Ck), mprev(Vr), mnext(Vr), mprev(Wr), mnext(Wr));
-        }
+        // level 0: nearest neighbours by DPP wave shifts
+        level(0, [&](const M2 &m) { return mprev(m); }, [&](const M2 &m) { return mnext(m); });
 #pragma unroll 1
         for (int lv = 1; lv < 5; ++lv) {
             const int lm_ = (lane - (1 << lv)) & 63, lp_ = (lane + (1 << lv)) & 63;
-            const M2 Bi = minv(Bk);
-            level(lv, mshf(Bi, lm_), mshf(Bi, lp_), mshf(Ak, lm_), mshf(Ak, lp_), mshf(Ck, lm_), mshf(Ck, lp_), mshf(Vr, lm_),
-                  mshf(Vr, lp_), mshf(Wr, lm_), mshf(Wr, lp_));
+            level(lv, [&](const M2 &m) { return mshf(m, lm_); }, [&](const M2 &m) { return mshf(m, lp_); });
         }
-        {   // level 5: stride 32 by v_permlane32_swap
-            const M2 Bi = minv(Bk);
-            M2 Bim, Bip, Akm, Akp, Ckm, Ckp, Vm, Vp, Wm, Wp;
-            mswap32(Bi, Bim, Bip); mswap32(Ak, Akm, Akp); mswap32(Ck, Ckm, Ckp); mswap32(Vr, Vm, Vp); mswap32(Wr, Wm, Wp);
-            level(5, Bim, Bip, Akm, Akp, Ckm, Ckp, Vm, Vp, Wm, Wp);
-        }
+        // level 5: stride 32 by v_permlane32_swap
+        level(5, [&](const M2 &m) { M2 dn, up; mswap32(m, dn, up); return dn; }, [&](const M2 &m) { M2 dn, up; mswap32(m, dn, up); return up; });
         const M2 Bfin = minv(Bk);
         put(BFIN, Bfin);
         const M2 Vk = mmul(Bfin, Vr), Wk = mmul(Bfin, Wr);
