@@ -249,12 +249,18 @@ struct Emitter {
         if (clamped) v = min_y;
         if (writer) o[0] = v;
     }
-    __device__ inline void put(int k, double total, double dx, bool writer)
+    // the sample as it is stored (scale, clamp) and its trace in the zone bookkeeping
+    __device__ inline double value(double total, double dx)
     {
         double v = total * dx * scale;
         rmin = fminf(rmin, (float)(fabs(v) * inv_first));
         clamped |= v < min_y;
         if (clamped) v = min_y;
+        return v;
+    }
+    __device__ inline void put(int k, double total, double dx, bool writer)
+    {
+        const double v = value(total, dx);
         if (writer) o[k] = v;
     }
 };
@@ -829,6 +835,9 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         }
     }
 
+    if constexpr (BK::kBlocksSamples) {
+        if (st == MTRPL_SOLVE_OK) bk.out_finish();
+    }
     if (st != MTRPL_SOLVE_OK) {
         // forward_solver.py:168: samples after the last solved time come from a zeroed state
         real zsig = (real)0;
@@ -836,6 +845,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         for (int r = 0; r < R; ++r) zsig += (bk.node(r) < L) ? signal_density_literal(p, meas, (real)0, (real)0) : (real)0;
         for (; io < nt; ++io) bk.out_sample(io, zsig);
         if constexpr (BK::kParksSamples) bk.out_flush();
+        if constexpr (BK::kBlocksSamples) bk.out_finish();
     } else if (tol_clamped) {
         st = MTRPL_SOLVE_OK_TOL_CLAMPED;
     }

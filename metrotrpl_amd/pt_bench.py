@@ -314,6 +314,30 @@ def pmc_fields(solves_per_launch=1024, kernel="solve_kernel_wave1"):
     return out
 
 
+def pmc_file_fields(suffix, solves_per_launch):
+    """traffic / occupancy figures of a kernel from the newest committed profiles/rNN_z_<suffix> (rocprofv3 --pmc
+    passes; not measured in this run)."""
+    import glob
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {"traffic": None, "traffic_source": None}
+    found = sorted(glob.glob(os.path.join(repo, "profiles", "r*_z_" + suffix)))
+    if not found:
+        return out
+    try:
+        z = json.load(open(found[-1]))
+        t = z.get("solve_kernel_bytes_per_launch")
+        if t is not None:
+            out["traffic"] = t * solves_per_launch / float(z.get("solves_per_launch", solves_per_launch))
+        out["traffic_source"] = f"profiles/{os.path.basename(found[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, one launch at a time)"
+        d = z.get("derived", {})
+        out["valu_active_frac"] = d.get("valu_active_fraction_of_wave_cycles")
+        out["parked_on_waitcnt_frac"] = d.get("parked_on_waitcnt_fraction_of_wave_cycles")
+        out["occupancy_waves_per_simd"] = d.get("occupancy_waves_per_simd")
+    except Exception:
+        pass
+    return out
+
+
 N_SIMD, CLOCK_HZ = 1024, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz max clock
 
 
