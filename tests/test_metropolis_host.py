@@ -277,3 +277,21 @@ def test_mu_constraint_draws_are_replayable(tmp_path):
     ambi = 2.0 / (1.0 / mu_n + 1.0 / mu_p)
     moved = outs[0].H.accept[:, 1:] == 1
     assert moved.any() and np.all(np.abs(ambi[moved] - 20.0) <= 3.0 + 1e-9)
+
+
+def test_stretches_cut_a_run_like_the_reference_checkpoints_it():
+    """metro()'s stretch iterator against the reference's loop arithmetic (metropolis.py:388-412: ending = min(start + freq,
+    num_iters); while ending <= num_iters: ...; if ending == num_iters: break; start = ending; ending = min(ending + freq, n))."""
+    from metrotrpl_amd.metropolis import _stretches
+
+    def reference(start, n, freq):
+        out, ending = [], min(start + freq, n)
+        while ending <= n:
+            out.append((start, ending, ending == n))
+            if ending == n:
+                break
+            start, ending = ending, min(ending + freq, n)
+        return out
+    for start, n, freq in ((0, 10, 3), (0, 10, 10), (0, 10, 25), (4, 10, 3), (9, 10, 1), (0, 1, 1), (0, 12, 4), (5, 5, 2)):
+        assert list(_stretches(start, n, freq)) == reference(start, n, freq), (start, n, freq)
+    assert list(_stretches(0, 7, 0)) == [(0, 7, True)]  # (a zero frequency would never end in the reference: one stretch here)

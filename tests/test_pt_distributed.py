@@ -170,6 +170,14 @@ def test_prefetched_iterations_walk_the_same_chain():
     assert seq.swap_attempts.sum() == (iters // 4) * (n_chains - 1) and seq.swap_accepts.sum() > 0
     assert pre.it == seq.it == iters
     assert len(calls_s) == 1 + iters
+    # every replica exchange is timed in three parts (bench.py reports them as exchange_ms), and a library call leaves the
+    # process's garbage collector as it found it unless asked (gc_freeze is opt-in)
+    for e in (seq, pre):
+        assert e.exchange_s["n"] == iters // 4 and all(e.exchange_s[k] >= 0.0 for k in ("wait", "gather", "replay"))
+        assert e.exchange_s["wait"] + e.exchange_s["gather"] + e.exchange_s["replay"] > 0.0
+        assert e.gc_freeze is False
+    import gc
+    assert gc.isenabled() and gc.get_freeze_count() == 0
     # the exchange falls after even iterations, so every pair (1,2), (3,4), ... goes out as one launch
     assert calls_p.count(3 * n_chains) == iters // 2 and len(calls_p) == 1 + iters // 2 + 1
     odd, _, calls_o = _run_counter(n_chains, 9, True, temper_freq=3)  # an exchange between 3 and 4: no pair there

@@ -6,7 +6,7 @@ T=$1
 SEC=${SECTIONS:-wave,c5,pt,acc}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # bench.py sets this itself, but under rocprofv3 the runtime is up before Python starts
-export GPU_MAX_HW_QUEUES=8
+export GPU_MAX_HW_QUEUES=16
 O=gpurun_out
 if [[ $SEC == *wave* ]]; then
 # ---- counters of the two builds of the wave kernel (each group in its own pass) ----
@@ -81,6 +81,10 @@ fi
 if [[ $SEC == *acc* ]]; then
 # ---- the held-out converged set, where the steps of a solve go ----
 timeout -k 10 200 python tools/heldout_table.py > $O/${T}_heldout.txt 2>/dev/null
+{ echo "== SPIKE backend (default)"; timeout -k 10 200 python tools/heldout_table.py --large; echo "== team backend (kernel_variant 1)"; timeout -k 10 200 python tools/heldout_table.py --large kernel_variant=1; } > $O/${T}_heldout_large.txt 2>/dev/null
+MTRPL_LIB_PATH=$PWD/metrotrpl_amd/lib/libmetrotrpl_amd_trace.so timeout -k 10 200 python tools/bind_trace.py 2>/dev/null | grep -v amdgpu.ids > $O/${T}_bind_trace.txt
+{ timeout -k 10 100 python tools/pt_chain_granularity.py 10 64; timeout -k 10 100 python tools/pt_chain_granularity.py 10 512; } 2>/dev/null | grep -v amdgpu.ids > $O/${T}_pt_chain_granularity.txt
+{ timeout -k 10 100 python tools/api_sweep.py 8192; for q in 8 16; do for a in "0 0" "3 2" "8 2"; do GPU_MAX_HW_QUEUES=$q timeout -k 10 100 python tools/api_queues.py $a; done; done; } 2>/dev/null | grep -v amdgpu.ids > $O/${T}_api_streams.txt
 MTRPL_LIB_PATH=$PWD/metrotrpl_amd/lib/libmetrotrpl_amd_trace.so timeout -k 10 200 python tools/startup_trace.py > $O/${T}_startup_trace.txt 2>/dev/null
 # ---- accuracy table, variant agreement, solve latency, PCIe-inclusive rate ----
 timeout -k 10 200 python tools/tail_table.py --json $O/${T}_tail_decades.json --settings shipped > $O/${T}_tail_decades.txt 2>/dev/null

@@ -1,12 +1,16 @@
-"""Per-decade errors and step counts on the held-out converged traces (tests/golden/heldout.npz) for one or more
-integrator-option settings (dev tool):  python tools/heldout_table.py "honor_hmax=0" "shape_factor=100,fun_weight=4" """
+"""Per-decade errors and step counts on the held-out converged traces (tests/golden/heldout.npz; --large: the nx > 128 set
+tests/golden/heldout_large.npz, through the SPIKE backend, or with kernel_variant=1 through the team backend) for one or more
+integrator-option settings (dev tool):  python tools/heldout_table.py [--large] "honor_hmax=0" "shape_factor=100,fun_weight=4" """
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from metrotrpl_amd import _lib as L
 from tests.test_gpu_heldout import solve_all, decade_table
-z = np.load(os.path.join(ROOT, "tests", "golden", "heldout.npz"))
+LARGE = "--large" in sys.argv
+if LARGE:
+    sys.argv.remove("--large")
+z = np.load(os.path.join(ROOT, "tests", "golden", "heldout_large.npz" if LARGE else "heldout.npz"))
 ctx = L.default_context()
 v = z["valid"]
 for setting in ["shipped"] + sys.argv[1:]:
@@ -27,3 +31,7 @@ for setting in ["shipped"] + sys.argv[1:]:
         for g_ in sorted(set(str(x) for x in z["group"])):
             m = v & (z["group"] == g_)
             print(f"     {g_:8s} {int(m.sum()):3d} traces, steps mean {steps[m].mean():6.0f} max {steps[m].max():6d}")
+        if LARGE:
+            for nx in sorted(set(int(x) for x in z["nx"])):
+                m = v & (z["nx"] == nx)
+                print(f"     nx {nx:4d}  {int(m.sum()):3d} traces, steps mean {steps[m].mean():6.0f} max {steps[m].max():6d}")

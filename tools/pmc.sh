@@ -3,7 +3,7 @@
 # the wave kernel: one 1024-solve launch at a time (wave1) and one 2048-solve launch at a time (wave2)
 T=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-export GPU_MAX_HW_QUEUES=8
+export GPU_MAX_HW_QUEUES=16
 O=gpurun_out
 B1="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --streams 1 --quick"
 B2="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --streams 1 --quick --batch 2048 --opt kernel_variant=3"

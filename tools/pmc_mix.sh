@@ -4,7 +4,7 @@
 # and the issue cost of the instruction classes on this device (tools/mb/rcp_rate.hip) -> gpurun_out/TAG_issue_cost.txt
 T=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-export GPU_MAX_HW_QUEUES=8
+export GPU_MAX_HW_QUEUES=16
 O=gpurun_out
 B2="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 --quick --batch 2048 --opt kernel_variant=3"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 --kernel-trace --output-format csv -d $O/pmc${T}_mix64 -- $B2 > $O/pmc${T}_mix1.log 2>&1

@@ -45,6 +45,10 @@ if b:
     pt = b.get("pt") or {}
     ptl = ", ".join(f"{k} chains {v['ms_per_iteration']:.2f} ms / iteration" for k, v in pt.items() if "ms_per_iteration" in v)
     acc = b.get("accuracy") or {}
+    api = b.get("api") or {}
+    if api.get("solve_batch"):
+        legs.append(f"`api.solve_batch` {api['solve_batch']['pinned_out']['solves_per_sec'] / 1e3:.1f} k host to host (pageable output "
+                    f"{api['solve_batch']['pageable_out']['solves_per_sec'] / 1e3:.1f} k), `api.dense_sampler` {api['dense_sampler']['samples_per_sec'] / 1e3:.1f} k samples/s")
     rows.append((f"`{T}_bench_config2.json`",
                  f"the `bench.py` line (K = {b['steps']}): **{b['value'] / 1e3:.1f} k solves/s**, {b['ms_per_step']:.3f} ms per 1024-solve step, "
                  f"{c['streams']} streams as drawn; mean / max integrator steps {c['mean_integrator_steps']:.0f} / {c['max_integrator_steps']}; "
@@ -83,6 +87,10 @@ for name in ("bench_pt512_1gpu.json", "bench_pt64_1gpu.json", "bench_pt512_1gpu_
         rows.append((f"`{T}_{name}`", f"`bench.py --workload pt`: {b['config']['chains']} chains, {b['ms_per_step']:.2f} ms per iteration = {b['value'] / 1e3:.1f} k proposals/s "
                                       f"(prefetch {b['config']['prefetch']}, {b['config']['chain_groups']} group(s), decisions on the {b['config'].get('decisions', 'host')})"))
 for name, what in (("tail_decades.txt", "per-decade accuracy table (config 2 / config-3 geometry)"), ("heldout.txt", "the held-out converged set, per decade"),
+                   ("heldout_large.txt", "the nx > 128 held-out converged set, per decade, through the SPIKE and the team backend"),
+                   ("bind_trace.txt", "which half of the goal-oriented error test sets the step size, per decade of time (diagnostic build)"),
+                   ("pt_chain_granularity.txt", "what a chain-granular PT pipeline could buy: sum over launches of the slowest chain against the slowest chain's own sum"),
+                   ("api_streams.txt", "`mtrpl_solve_batch` host to host at B = 8192: sub-launch size x streams; and inside processes that own other streams, with 8 and 16 hardware queues"),
                    ("startup_trace.txt", "where the steps of a solve go along the time axis"), ("slow_solves.txt", "the slowest solves of the config-2 batch"),
                    ("variant_agreement.txt", "default kernel vs fp64-block kernel on 8192 draws"), ("solve_latency.txt", "latency of the drop-in `solve()`"),
                    ("config5_sweep.txt", "config 5: fp32 / fp64 tolerance sweep on this build"), ("issue_cost.txt", "issue cost of the instruction classes"),

@@ -5,7 +5,7 @@ swap is compared (dev tool).
 import os
 import sys
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

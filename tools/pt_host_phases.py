@@ -5,7 +5,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # as bench.py does: every chain group's stream on a hardware queue of its own
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # as bench.py does: every chain group's stream on a hardware queue of its own
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
