@@ -138,6 +138,8 @@ def lib():
                 pass
             L = C.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
+                if os.environ.get("MTRPL_LIB_PATH") and not hasattr(L, name):
+                    continue  # (an older build of the library named explicitly for an A/B run: it has what it has)
                 fn = getattr(L, name)
                 fn.restype = res
                 fn.argtypes = args

@@ -110,7 +110,7 @@ struct SolveTuning {
 // The shipped settings as compile-time constants: a kernel instantiated on this type instead of on the
 // run-time struct keeps none of them in (spilled) scalar registers.  Single source of the defaults.
 struct DefaultTune {
-    static constexpr double rtol_scale = 0.1, rtol_cap = 2.4e-9, rtol_floor = 3e-10, rtol_min = 3e-11, rtol_force = 0.0;
+    static constexpr double rtol_scale = 0.1, rtol_cap = 2e-9, rtol_floor = 2e-10, rtol_min = 3e-11, rtol_force = 0.0;
     static constexpr double atol_rel = 1e-4, atol_rel_np = 1e-9;
     static constexpr int max_steps = 2000000;
     static constexpr double newton_tol = 0.1;

@@ -27,6 +27,10 @@ tolerance (1e-24 on every density, 1e-17 on the field); the oracle's own uncerta
 same solves at density ATOL 1e-26 and at RTOL 3e-13 (`u_oracle[trace, decade]`).
 
     python tests/golden/make_heldout.py            (about 25 minutes on 8 cores)
+
+Round 5 added a SECOND draw of the same recipe (`--second`: seed W.SEED + 606 -> heldout2.npz), generated after that round's
+two changes to the error control (the field out of the controller's norms, no growth cap after a rejection) had been made and
+never used to choose anything: heldout.npz stays frozen, the set of unseen traces grows.
 """
 import os
 import sys
@@ -64,8 +68,13 @@ def draw_state(rng, box=None):
             return s
 
 
+SECOND = "--second" in sys.argv
+THIRD = "--third" in sys.argv   # seed W.SEED + 707 -> heldout3.npz: drawn after the internal tolerance was set with heldout2 in view
+OUT = "heldout3.npz" if THIRD else ("heldout2.npz" if SECOND else "heldout.npz")
+
+
 def cases():
-    rng = np.random.default_rng(W.SEED + 404)
+    rng = np.random.default_rng(W.SEED + (707 if THIRD else (606 if SECOND else 404)))
     t_uniform = np.linspace(0, 2000, 1001)
     out = []
 
@@ -161,7 +170,7 @@ if __name__ == "__main__":
     print("valid", int(valid.sum()), "of", n)
     print("oracle self-uncertainty, max over valid traces per decade:", " ".join(f"{v:.1e}" for v in u[valid].max(axis=0)))
     np.savez_compressed(
-        os.path.join(HERE, "heldout.npz"), names=np.array(",".join(NAMES)), units=UNITS, valid=valid,
+        os.path.join(HERE, OUT), names=np.array(",".join(NAMES)), units=UNITS, valid=valid,
         group=np.array([c["group"] for c in CASES]), states=np.array([c["state"] for c in CASES]),
         thickness=np.array([c["thickness"] for c in CASES]), nx=np.array([c["nx"] for c in CASES]),
         nt=np.array([len(c["t"]) for c in CASES]), meas=np.array([c["meas"] for c in CASES]),
@@ -169,4 +178,4 @@ if __name__ == "__main__":
         ini_mode=np.array([c["ini_mode"] for c in CASES]), ini=ini, t=t, sig=sig, u_oracle=u,
         u_oracle_settings=np.array("max over (RTOL 1e-12, density ATOL 1e-26) and (RTOL 3e-13, density ATOL 1e-24) of "
                                    "|trace - primary| / |primary|, per trace and decade 0..12"))
-    print("wrote heldout.npz")
+    print("wrote", OUT)

@@ -74,10 +74,16 @@ def decade_table(z, sig, n_dec=11):
     return out
 
 
+# heldout.npz: frozen since round 4.  heldout2.npz: a second draw of the same recipe (other seed), generated in round 5 AFTER that
+# round's changes to the error control (the field out of the norms, no growth cap): it passed at 8.5e-7 where round 4's build had
+# 5.7e-7 -- the margins of the gating fixtures had not told -- and the internal tolerance went from 2.4e-9 to 2e-9 (and its policy
+# floor with it) with that in view.  heldout3.npz: a third draw, generated after that and used to choose nothing.  The set of
+# unseen traces grows; no set is re-drawn.
+@pytest.mark.parametrize("fixture", ["heldout.npz", "heldout2.npz", "heldout3.npz"])
 @pytest.mark.parametrize("variant", [0, 3])  # the default build | two solves per SIMD
-def test_heldout_traces_decade_by_decade(variant):
+def test_heldout_traces_decade_by_decade(variant, fixture):
     from metrotrpl_amd import _lib as L
-    fn = os.path.join(G, "heldout.npz")
+    fn = os.path.join(G, fixture)
     z = np.load(fn)
     assert int(z["valid"].sum()) >= 128
     ctx = L.default_context()
