@@ -39,6 +39,7 @@ struct SpikeBackendT {
     static constexpr int R = 2, V = 6, T = 64 * W;
     static constexpr bool TRAPS = false;
     static constexpr bool kFieldInNorms = false;  // the field components in the controller's norms (solve_core.hpp)
+    static constexpr bool kOrderRowInVgpr = false;
     static constexpr bool kBlocksSamples = false;
     static constexpr bool kParksSamples = true;  // out_sample() parks, out_flush() emits
     static constexpr int NI = W - 1;       // interfaces

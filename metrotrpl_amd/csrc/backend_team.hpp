@@ -26,6 +26,7 @@ struct TeamBackend {
     static constexpr int R = 2, V = TRAPS_ ? 8 : 6, T = 64 * W;
     static constexpr bool TRAPS = TRAPS_;
     static constexpr bool kFieldInNorms = false;  // the field components in the controller's norms (solve_core.hpp)
+    static constexpr bool kOrderRowInVgpr = false;
     static constexpr bool kBlocksSamples = false;
     static constexpr bool kParksSamples = false;
     static constexpr int LEVELS = 6 + (W >= 2 ? 1 : 0) + (W >= 4 ? 1 : 0);  // PCR levels over T rows

@@ -30,13 +30,14 @@ constexpr int kFactorLdsBytesF32 = 20 * 64 * 16;     // 20480 B per wave with bl
 // right-hand side of the re-solve stay fp64.  The blocks only define the approximate inverse the simplified
 // Newton iteration applies to an fp64 residual: the iteration converges to the same corrector solution
 // (measured: same step counts, +0.7 % Newton iterations, per-decade accuracy table unchanged).
-template <bool F32BLK>
+template <bool F32BLK, bool ROWV = false>
 struct WaveBackendT {
     using real = double;
     static constexpr int R = 2, V = 6;
     static constexpr bool TRAPS = false;
     static constexpr bool kFieldInNorms = false;  // the field components in the controller's norms (solve_core.hpp)
     static constexpr bool kParksSamples = false;  // out_sample() parks, out_flush() emits
+    static constexpr bool kOrderRowInVgpr = ROWV;  // the order table's row by v_readlane (solve_core.hpp: OrderRow): the one-per-SIMD kernel
     static constexpr bool kBlocksSamples = true;  // the samples leave in blocks of 64: integrate() calls out_finish() at the end
 
     Par p;
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if ((int64_t)blockIdx.x >= B) return;
     const int64_t sidx = blockIdx.x;
     __shared__ float4 fac_lds[kFactorLdsBytesF32 / 16];
-    WaveBackendT<true> bk(threadIdx.x & 63, fac_lds);
+    WaveBackendT<true, true> bk(threadIdx.x & 63, fac_lds);
     if (CT)
         integrate(bk, descs[sidx], ini, tsteps, out, status, stats, sidx, DefaultTune{}, clk0_);
     else

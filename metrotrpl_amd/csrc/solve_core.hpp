@@ -34,6 +34,7 @@
 // hardware sqrt / rcp / log / exp tripled their number.  Everything order-dependent comes from one 128-byte row
 // of a table in constant memory (scalar loads), not from a switch over the order.
 #pragma once
+#include <cstddef>
 #include <type_traits>
 
 #include "model_physics.hpp"
@@ -170,6 +171,50 @@ constexpr NqRows nq_make_rows()
     return T;
 }
 static __constant__ NqRows kNq = nq_make_rows();
+
+// The row of the current order, two ways.  OrderRow<false>: scalar loads from constant memory where a value is needed --
+// free for the vector ALU, which is what a SIMD shared by two solves is short of.  OrderRow<true>: the 16 doubles of the row sit
+// in lanes 0-15 of one register pair (one vector load per change of order) and a value reaches the scalar unit by
+// v_readlane -- no scalar-memory round trip (100-200 cycles, three or four of them exposed per step) for a wave that has its
+// SIMD to itself and nothing else to do while it waits.  Same values either way.
+template <bool IN_VGPR> struct OrderRow;
+template <> struct OrderRow<false> {
+    const NqRow *r;
+    __device__ inline void load(int order, int) { r = &kNq.row[order]; }
+    __device__ inline double el(int j) const { return r->el[j]; }
+    __device__ inline double inv_t1() const { return r->inv_t1; }
+    __device__ inline double inv_t2() const { return r->inv_t2; }
+    __device__ inline double inv_t3() const { return r->inv_t3; }
+    __device__ inline double el_up() const { return r->el_up; }
+    __device__ inline double elK() const { return r->elK; }
+    __device__ inline float nik0() const { return r->nik0; }
+    __device__ inline float nik1() const { return r->nik1; }
+    __device__ inline float nik2() const { return r->nik2; }
+    __device__ inline float inv_qp1() const { return r->inv_qp1; }
+};
+template <> struct OrderRow<true> {
+    double v;  // lane j < 16: double j of the row (el[0..5], inv_t1..3, el_up, elK, (nik0, nik1), (nik2, inv_qp1), pad)
+    __device__ inline void load(int order, int lane) { v = reinterpret_cast<const double *>(&kNq.row[order])[lane & 15]; }
+    __device__ inline double d(int j) const { return lane_value(v, j); }
+    __device__ inline float f(int j, int half) const
+    {
+        union { double d; float q[2]; } u;
+        u.d = lane_value(v, j);
+        return u.q[half];
+    }
+    __device__ inline double el(int j) const { return d(j); }
+    __device__ inline double inv_t1() const { return d(6); }
+    __device__ inline double inv_t2() const { return d(7); }
+    __device__ inline double inv_t3() const { return d(8); }
+    __device__ inline double el_up() const { return d(9); }
+    __device__ inline double elK() const { return d(10); }
+    __device__ inline float nik0() const { return f(11, 0); }
+    __device__ inline float nik1() const { return f(11, 1); }
+    __device__ inline float nik2() const { return f(12, 0); }
+    __device__ inline float inv_qp1() const { return f(12, 1); }
+};
+static_assert(offsetof(NqRow, inv_t1) == 48 && offsetof(NqRow, el_up) == 72 && offsetof(NqRow, elK) == 80 && offsetof(NqRow, nik0) == 88 &&
+              offsetof(NqRow, nik2) == 96, "OrderRow<true> reads the row by these slots");
 
 // z <- A z (Pascal triangle), in place; and its inverse
 template <int K, int V, class T>
@@ -485,6 +530,8 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
         for (int v = 0; v < V; ++v) z[k][v] = (k == 0) ? y[v] : ((k == 1) ? h * f[v] : (real)0);
 
     int order = 1, n_equal = 0;
+    OrderRow<BK::kOrderRowInVgpr> nq;
+    nq.load(order, lane64);
     real t = (real)0;
     int have_fac = 0;
     ctl rate_prev = 1.0f;
@@ -514,13 +561,13 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             st = MTRPL_SOLVE_STOPPED_EARLY;
             break;
         }
-        const NqRow &nq = kNq.row[order];
+        if constexpr (!BK::kOrderRowInVgpr) nq.load(order, lane64);
         // the order / step-size selection runs after this step if it is accepted with n_equal >= order:
         // its two grid sums then travel with the Newton norms instead of costing a reduction of their own
         const bool will_select = n_equal >= order;
         // predictor: z <- A z; z[0] is the predicted state, z[1] the predicted h*y'
         nq_predict<5, V>(z);
-        const real el0 = (real)nq.el[0];
+        const real el0 = (real)nq.el(0);
         const real c = h * el0;
         // steps that end before early_frac x the first sample time get early_factor x the local tolerance: the
         // norms of such a step are scaled instead of its weights
@@ -608,7 +655,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                 }
                 if (will_select) {
                     // stode: ddn from the last Nordsieck row (after the correction), dup from acor - acor_prev
-                    const float elK = (float)nq.elK;
+                    const float elK = (float)nq.elK();
                     // (a switch with one loop per case: a select chain over z[1..5][v] is turned into a load with a
                     // run-time row index, and the whole history then lives in memory)
 #define MTRPL_DDN_ROW(J) for (int v = 0; v < V; ++v) { if (!in_norm(v)) continue; const float q_ = fmaf(elK, acf[v], (float)z[J][v]) * isc[v]; s4[2] = fmaf(q_, q_, s4[2]); }
@@ -667,7 +714,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                 const bool rate_ok = (k > 0) || (rate_prev < 0.9f && rate_age < tune.rate_max_age);
                 if (negligible || (rate_ok && rate < 1.0f && rate * dn < newton_tol * (1.0f - rate))) {
                     converged = 1;
-                    dsm = nscale * __builtin_amdgcn_sqrtf(s4[1] * inv_S) * (ctl)nq.inv_t2;
+                    dsm = nscale * __builtin_amdgcn_sqrtf(s4[1] * inv_S) * (ctl)nq.inv_t2();
                     if (goal) {
                         // RMS norm against shape_factor x the tolerance, mass component against the tolerance / fun_weight
                         // (relative to the excess while that is above mass_floor x the equilibrium density, to that level below --
@@ -675,7 +722,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                         // a hundredth of n0, held-out trace 17)
                         // (eleven decades down the tolerance is relaxed 30 000-fold, N may sit a thousandth BELOW n0 and the sum
                         // cross zero: nothing is resolved there and there is no mass to test against -- the shape test remains)
-                        const ctl dfun = (sfm[1] > 0.0f && !bk.deep()) ? nscale * (ctl)tune.fun_weight * fabsf(sfm[0]) * __builtin_amdgcn_rcpf(rtol_f * sfm[1]) * (ctl)nq.inv_t2 : 0.0f;
+                        const ctl dfun = (sfm[1] > 0.0f && !bk.deep()) ? nscale * (ctl)tune.fun_weight * fabsf(sfm[0]) * __builtin_amdgcn_rcpf(rtol_f * sfm[1]) * (ctl)nq.inv_t2() : 0.0f;
                         const ctl dboth = fmaxf(dsm * (ctl)(1.0 / tune.shape_factor), dfun);
                         rho = (dsm > 0.0f) ? dboth * __builtin_amdgcn_rcpf(dsm) : 1.0f;
                         dsm = dboth;
@@ -707,7 +754,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             n_bad += converged ? (((n_bad & 0xffff) != 0xffff) ? 1 : 0) : (1 << 16);
             fails++;
             if (converged) since_rej = 0;
-            facz = converged ? (real)fmaxf(0.2f, safety * pow_ctl(dsm, -nq.inv_qp1)) : (real)0.5;
+            facz = converged ? (real)fmaxf(0.2f, safety * pow_ctl(dsm, -nq.inv_qp1())) : (real)0.5;
             nq_retract<5, V>(z);
 #pragma unroll
             for (int v = 0; v < V; ++v) acor[v] = (real)0;
@@ -722,7 +769,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             t += h;
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                const real elj = (real)nq.el[j];  // zero above the order: those rows stay zero
+                const real elj = (real)nq.el(j);  // zero above the order: those rows stay zero
 #pragma unroll
                 for (int v = 0; v < V; ++v) z[j][v] += elj * acor[v];
             }
@@ -782,10 +829,10 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                 {
                     // (goal-oriented test: the neighbouring orders' estimates are taken to split into shape and mass
                     // like this order's)
-                    const ctl ddn = rho * nscale * (ctl)nq.inv_t1 * __builtin_amdgcn_sqrtf(ssel0 * inv_S);
-                    const ctl dup = rho * nscale * (ctl)nq.inv_t3 * __builtin_amdgcn_sqrtf(ssel1 * inv_S);
+                    const ctl ddn = rho * nscale * (ctl)nq.inv_t1() * __builtin_amdgcn_sqrtf(ssel0 * inv_S);
+                    const ctl dup = rho * nscale * (ctl)nq.inv_t3() * __builtin_amdgcn_sqrtf(ssel1 * inv_S);
                     ctl x = (lane64 == 0) ? ddn : ((lane64 == 1) ? dsm : dup);
-                    const ctl e = (lane64 == 0) ? nq.nik0 : ((lane64 == 1) ? nq.nik1 : nq.nik2);
+                    const ctl e = (lane64 == 0) ? nq.nik0() : ((lane64 == 1) ? nq.nik1() : nq.nik2());
                     x = fminf(fmaxf(x, 1e-30f), 1e30f);
                     const ctl pw = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * e);
                     fm = (order > 1) ? lane_value(pw, 0) : 0.0f;
@@ -818,7 +865,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
             // Row j = 1..5 is scaled by fac^j; on an order increase the new last row is acor * l_q / (q+1) (times
             // fac^(q+1)), on an order decrease the dropped row is zeroed: z[j] <- kf[j] z[j] + af[j] acor, wave-uniform
             // kf, af (acor is zero after a discarded attempt).
-            const real el_up = (real)nq.el_up;
+            const real el_up = (real)nq.el_up();
             real r = (real)1;
 #pragma unroll
             for (int j = 1; j < 6; ++j) {
@@ -827,6 +874,9 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                 const real af = (qn > order && j == qn) ? el_up * r : (real)0;
 #pragma unroll
                 for (int v = 0; v < V; ++v) z[j][v] = kf * z[j][v] + af * acor[v];
+            }
+            if constexpr (BK::kOrderRowInVgpr) {
+                if (qn != order) nq.load(qn, lane64);
             }
             order = qn;
             h *= facz;
