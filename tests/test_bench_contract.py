@@ -171,3 +171,61 @@ def test_round4_bench_line_tells_the_whole_story():
     c5 = json.loads(open(path.replace("bench_config2", "bench_config5")).read().strip().splitlines()[-1])
     assert c5["config"]["nx"] == 512 and c5["config"]["all_solves_ok"] is True and "spike" in c5["roofline"]["kernel"]
     assert c5["single_stream"]["solves_per_sec"] < c5["value"]
+
+
+def test_round5_bench_line_tells_the_whole_story():
+    """The newest committed round-5 line (tools/final_profiles.sh on the MI355X box): what VERDICT r4 asked of the line itself --
+    the product API timed host to host (`api`), the spread of the per-launch kernel brackets, the exchange timed in three parts,
+    every host core accounted for in `cpu_baseline.all_cores`, a current source for the issue costs -- next to everything the
+    round-4 line carried; and config 5's line prices its roofline with the kernel's own duration and says what it moves."""
+    import glob
+    import json
+    path = sorted(glob.glob(os.path.join(REPO, "profiles", "r05_?_bench_config2.json")))[-1]
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    assert d["metric"] == "trpl_forward_solves_per_sec" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and d["n_gpus"] == 1 and d["data"] == "synthetic"
+    cfg = d["config"]
+    assert cfg["as_drawn"] is True and cfg["all_solves_ok"] is True and "model" not in cfg
+    assert cfg["solves_per_gpu_per_step"] == 1024 and cfg["nx"] == 128 and cfg["nt_out"] == 1001
+    assert cfg["mean_integrator_steps"] <= 760 and cfg["max_integrator_steps"] <= 1250  # (round 4: 801 / 1259)
+    assert abs(d["value"] - 1024 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"] and d["value"] >= 6.5e5  # VERDICT r4 next 1
+    for k in ("single_stream", "sorted_by_measured_cost", "fp64_linear_algebra"):
+        leg = d[k]
+        assert leg["all_solves_ok"] is True and leg["solves_per_sec"] > 2e5, k
+    assert d["single_stream"]["kernel_ms_min"] <= d["single_stream"]["kernel_ms"] <= d["single_stream"]["kernel_ms_max"]
+    assert d["single_stream"]["solves_per_sec"] < d["value"] < d["sorted_by_measured_cost"]["solves_per_sec"]
+    for b2 in ("2048", "4096"):
+        assert d["one_launch"][b2]["all_solves_ok"] is True
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - 6174168 * 1024 / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["kernel_ms_min"] <= r["kernel_ms"] <= r["kernel_ms_max"] and r["kernel"] == "solve_kernel_wave2"
+    assert r["traffic"] and r["traffic"] < 2 * 8531784 * 1.2  # PMC bytes per launch close to the compulsory figure
+    v = r["valu_issue"]
+    assert 0.3 < v["frac"] < 1.0 and 4e5 < v["insts_per_solve"] < 7e5 and 0.5 < v["throughput"]["frac_of_bound"] < 1.0
+    assert "r05" in v["throughput"]["source"]  # (round 4's line still cited round 3's issue-cost file)
+    # the product API, host to host (VERDICT r4 next 4: >= 450 k solves/s PCIe-inclusive, >= 70 k samples/s)
+    api = d["api"]
+    sb = api["solve_batch"]
+    assert sb["solves"] == 8192 and sb["pinned_out"]["all_solves_ok"] and sb["pageable_out"]["all_solves_ok"]
+    assert sb["pinned_out"]["solves_per_sec"] >= 4.5e5 and sb["pageable_out"]["solves_per_sec"] >= 4.0e5
+    assert api["dense_sampler"]["samples_per_sec"] >= 7e4 and api["dense_sampler"]["one_chunk_at_a_time"]["same_values"] is True
+    for chains in ("64", "512"):
+        p = d["pt"][chains]
+        assert p["chains"] == int(chains) and p["ms_per_iteration"] > 0 and p["collectives_per_iteration"] <= 1.0
+        assert abs(p["proposals_per_sec"] - int(chains) / (p["ms_per_iteration"] * 1e-3)) < 1e-6 * p["proposals_per_sec"]
+        assert p["exchanges_timed"] >= 1 and set(p["exchange_ms"]) == {"wait", "gather", "replay"}
+    assert d["pt"]["64"]["ms_per_iteration"] <= 2.4 and d["pt"]["512"]["ms_per_iteration"] <= 6.7  # round 4's figures
+    assert d["pt"]["64"]["cpu_baseline"]["kind"] == "port"
+    acc = d["accuracy"]
+    assert acc["all_ok"] is True and max(acc["max_rel_err_per_decade_0_to_8"]) < 1e-6
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "solves/s" and c["value"] > 0
+    assert c["all_cores"]["cores"] >= 1 and c["all_cores"]["cores_available"] >= c["all_cores"]["cores"]
+    c5 = json.loads(open(path.replace("bench_config2", "bench_config5")).read().strip().splitlines()[-1])
+    assert c5["config"]["nx"] == 512 and c5["config"]["all_solves_ok"] is True and "spike" in c5["roofline"]["kernel"]
+    assert c5["value"] >= 7.5e4 and c5["single_stream"]["solves_per_sec"] < c5["value"]  # VERDICT r4 next 2
+    r5 = c5["roofline"]
+    assert abs(r5["kernel_ms"] - c5["single_stream"]["kernel_ms"]) < 1e-9  # priced with the kernel's own duration ...
+    assert r5["in_flight"]["kernel_ms"] > r5["kernel_ms"]                   # ... the four-in-flight bracket beside it
+    assert r5["traffic"] is not None and "r05" in r5["traffic_source"]

@@ -17,6 +17,7 @@ tools/pmc_mix.sh $T > $O/${T}_pmc_mix.log 2>&1
 cp $O/hbm_traffic_${T}_wave1.json profiles/hbm_traffic.json
 cp $O/hbm_traffic_${T}_wave2.json profiles/hbm_traffic_wave2.json
 cp $O/hbm_traffic_${T}_mix_wave2.json profiles/hbm_traffic_mix_wave2.json
+cp $O/${T}_issue_cost.txt profiles/${T}_issue_cost.txt
 # ---- the contract line (all legs: single stream, as given, sorted, fp64 linear algebra, PT) ----
 timeout -k 10 500 python bench.py --steps 30 --warmup 3 > $O/${T}_bench_config2.json 2> $O/${T}_bench.err
 # ... and over the K the driver times (its command line: --gpus 1 --steps 20 --warmup 5)
@@ -30,16 +31,18 @@ cp $O/prof_$T/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_config2.csv
 cp $O/prof_${T}s1/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_config2_one_stream.csv
 fi
 if [[ $SEC == *c5* ]]; then
-# ---- config 5 (nx = 512): contract line, kernel statistics, counters of the SPIKE kernel ----
-timeout -k 10 300 python bench.py --workload config5 --steps 10 --warmup 2 > $O/${T}_bench_config5.json 2>> $O/${T}_bench.err
+# ---- config 5 (nx = 512): counters of the SPIKE kernel first (the contract line quotes its traffic from the summary), then
+# the contract line and the kernel statistics ----
 C5="python3 bench.py --workload config5 --steps 4 --warmup 1"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${T}c5 -- $C5 > $O/prof_${T}c5.log 2>&1
-cp $O/prof_${T}c5/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_config5.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc${T}c5_fetch -- $C5 > $O/pmc${T}c5_1.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc${T}c5_write -- $C5 > $O/pmc${T}c5_2.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc${T}c5_sq -- $C5 > $O/pmc${T}c5_3.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/pmc${T}c5_sq2 -- $C5 > $O/pmc${T}c5_4.log 2>&1
 python tools/pmc_summary.py "solve_kernel_spike<" $O/hbm_traffic_${T}_spike4.json $O/pmc${T}c5_fetch $O/pmc${T}c5_write $O/pmc${T}c5_sq $O/pmc${T}c5_sq2 > $O/${T}_pmc_team.log 2>&1
+cp $O/hbm_traffic_${T}_spike4.json profiles/${T}_pmc_spike4.json
+timeout -k 10 300 python bench.py --workload config5 --steps 10 --warmup 2 > $O/${T}_bench_config5.json 2>> $O/${T}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${T}c5 -- $C5 > $O/prof_${T}c5.log 2>&1
+cp $O/prof_${T}c5/*/*_kernel_stats.csv $O/${T}_kernel_stats_bench_config5.csv
 fi
 if [[ $SEC == *pt* ]]; then
 # ---- the parallel-tempering ensembles: contract lines, kernel statistics, counters of the likelihood kernel ----
