@@ -189,7 +189,8 @@ def _pt_leg(rank, world, local, dev, with_cpu, use_dist=False):
             return ok
         import torch
         import torch.distributed as dist
-        flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dev)
+        from metrotrpl_amd import pt as _pt
+        flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=_pt.coll_device(dev))
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         return int(flag.item()) == 0
 
@@ -318,7 +319,7 @@ def spawn_ranks(n):
     import subprocess
     import torch
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and os.environ.get("MTRPL_REHEARSE_ONE_GPU") != "1":
         print(f"bench.py: --gpus {n} but {have} GPU(s) visible; the HIP path has no CPU fallback", file=sys.stderr)
         return 3
     with socket.socket() as s:  # a free rendezvous port on the loop-back interface
@@ -397,6 +398,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # MTRPL_REHEARSE_ONE_GPU=1: every rank on device 0, process group `gloo` -- a rehearsal of the N > 1 control flow (the
+    # rank-0-only legs, the hand-overs between them, the assembly of the line) on a one-GPU box; its numbers mean nothing
+    rehearse = os.environ.get("MTRPL_REHEARSE_ONE_GPU") == "1"
+    if rehearse:
+        local = 0
     # one rank needs no process group; MTRPL_FORCE_DIST=1 makes a 1-rank run go through RCCL
     # anyway (rehearsal of the N > 1 code path on a one-GPU box)
     use_dist = world > 1 or os.environ.get("MTRPL_FORCE_DIST") == "1"
@@ -423,9 +429,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
-    from metrotrpl_amd import _lib as L, batch, workloads as W
+    from metrotrpl_amd import _lib as L, batch, pt as _pt, workloads as W
     if a.workload == "pt":
         from metrotrpl_amd import pt_bench
         line = pt_bench.run(a, rank, world, local, dev, cpu_baseline_fn=cpu_baseline_pt)
@@ -500,7 +509,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if use_dist:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64, device=_pt.coll_device(dev))
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         ok = all(bool((outs[q][1] == 0).all().item()) and bool(torch.isfinite(outs[q][0]).all().item())

@@ -9,6 +9,7 @@ import time
 import numpy as np
 
 from . import _lib as L
+from . import pt as _pt
 from . import batch
 from . import workloads as W
 from .pt_bench import HBM_PEAK_GBS, algorithmic_bytes
@@ -74,7 +75,7 @@ def run(a, rank, world, local, dev):
         torch.cuda.synchronize()
         dt_ = time.perf_counter() - t0
         if use_dist:
-            tt = torch.tensor([dt_], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt_], dtype=torch.float64, device=_pt.coll_device(dev))
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_ = float(tt.item())
         ok_ = all(bool((outs[q][1] == 0).all().item()) and bool(torch.isfinite(outs[q][0]).all().item())

@@ -170,6 +170,25 @@ LOCAL_ONLY = object()  # `group` of a ONE-rank ensemble that must not touch the 
 #                        one-GPU legs inside an N-rank job): no collective is issued, whatever torch.distributed has set up
 
 
+def all_gather_rows(recv, send, group=None):
+    """dist.all_gather_into_tensor -- through RCCL on device tensors; staged through the host where the process group is
+    `gloo` and the tensors live on a GPU (the two-rank rehearsal of bench.py on a one-GPU box: gloo gathers host memory)."""
+    import torch.distributed as dist
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        r = recv.cpu()
+        dist.all_gather_into_tensor(r, send.cpu(), group=group)
+        recv.copy_(r)
+        return
+    dist.all_gather_into_tensor(recv, send, group=group)
+
+
+def coll_device(dev, group=None):
+    """Where the small tensors of a barrier-side collective (a maximum over the ranks, a failure flag) should live: on the GPU
+    for RCCL, on the host for `gloo` (bench.py's one-GPU rehearsal of the N > 1 path)."""
+    import torch.distributed as dist
+    return "cpu" if (dist.is_initialized() and dist.get_backend(group) == "gloo") else dev
+
+
 def _single(world, group):
     """One rank and nothing to gather through: no process group initialised (or the caller said LOCAL_ONLY).  A one-rank
     group that WAS set up (MTRPL_FORCE_DIST=1, tests/gpu_ensemble_child.py --dist 1) does go through the collective."""
@@ -207,7 +226,7 @@ class TableGather:
                     send[:, :self.c] = local.view(self.G, self.c, self.nT)
                     send = send.view(self.G * mx, self.nT)
                 dev_result = torch.empty((world * self.G * mx, self.nT), dtype=local.dtype, device=local.device)
-                dist.all_gather_into_tensor(dev_result, send, group=group)
+                all_gather_rows(dev_result, send, group)
             if dev_result.is_cuda and stream is not None:
                 self.pool_key = (tuple(dev_result.shape), dev_result.dtype)
                 free = _PINNED.setdefault(self.pool_key, [])
@@ -446,7 +465,7 @@ class PTEnsemble:
         send[:c, :nT] = self.cur_tab
         send[:c, nT:] = torch.from_numpy(host).to(dev)
         recv = torch.empty((self.world * mx, nT + npar + 1), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(recv, send, group=self.group)
+        all_gather_rows(recv, send, self.group)
         self.n_collectives += 1
         arr = recv.cpu().numpy().reshape(self.world, mx, nT + npar + 1)
         full = np.concatenate([arr[r, :b[1] - b[0]] for r, b in enumerate(self.blocks)], axis=0)
@@ -473,11 +492,16 @@ class PTEnsemble:
                 # the accepted rows move into cur_tab on a stream of their own: nothing reads cur_tab before the next
                 # exchange, so that work has no place in front of the group's next launch
                 side = c[("side", g)] = {"side": torch.cuda.Stream(device=dev)}
-            c[key] = {"col": torch.from_numpy(np.tile(sel, G)).to(dev),
-                      "rows": torch.from_numpy(np.ascontiguousarray(sel - self.lo)).to(dev),
-                      "mask_host": torch.zeros((2, max(1, sel.shape[0])), dtype=torch.bool, pin_memory=pin),
-                      "mask_dev": torch.zeros((2, max(1, sel.shape[0])), dtype=torch.bool, device=dev),
-                      "side": side["side"] if side else None, "side_done": None}
+            # (made on the group's stream: `zeros` is a fill kernel, and everything that touches these tensors later runs on
+            # that stream or behind an event of it -- torch's side streams do not wait for the default stream)
+            with (torch.cuda.stream(self.streams[g]) if (pin and self.streams[g] is not None) else _Nothing()):
+                c[key] = {"col": torch.from_numpy(np.tile(sel, G)).to(dev),
+                          "rows": torch.from_numpy(np.ascontiguousarray(sel - self.lo)).to(dev),
+                          "mask_host": torch.zeros((2, max(1, sel.shape[0])), dtype=torch.bool, pin_memory=pin),
+                          "mask_dev": torch.zeros((2, max(1, sel.shape[0])), dtype=torch.bool, device=dev),
+                          "side": side["side"] if side else None, "side_done": None}
+                if pin and self.streams[g] is not None:
+                    self.streams[g].synchronize()  # (built once per ensemble: the side stream may use them at once)
         return c[key]
 
     def _sync_logll(self):
@@ -763,12 +787,17 @@ class _DecidePipe:
                 srow = np.asarray(self.ev.plan_packed(np.tile(self.s, (G, 1))), dtype=np.int64)
             else:
                 srow = None
-            idx = torch.from_numpy(np.stack([self.sel - ens.lo, self.sel]).astype(np.int32)).to(dev)
-            self.row32, self.col32 = idx[0], idx[1]
-            self.rows, self.col = idx[0].long(), idx[1].long()
             self.fast = hasattr(self.ev, "decide") and hasattr(self.ev, "select")
             self.srow = srow
             with self._on():
+                # (the index tensors are made ON THE GROUP'S STREAM: `.long()` is a kernel, and the gather below -- like every
+                # later launch of this group -- runs on that stream, which does not wait for torch's default stream.  Made
+                # on the default stream, as they were until round 5, the gather could read them before the conversion had
+                # written them: an out-of-range index and a memory fault, seen once two ranks shared a device in the
+                # rehearsal of bench.py's N > 1 path)
+                idx = torch.from_numpy(np.stack([self.sel - ens.lo, self.sel]).astype(np.int32)).to(dev)
+                self.row32, self.col32 = idx[0], idx[1]
+                self.rows, self.col = idx[0].long(), idx[1].long()
                 self.cur_ll = ens.cur_tab[self.rows, self.col].clone()  # the chains' log-likelihoods at their own temperatures
                 self.outcome = None
                 self.chain_of_row = None  # built with the first package (the evaluator's M is not known here)

@@ -17,6 +17,7 @@ import time
 import numpy as np
 
 from . import _lib as L
+from . import pt as _pt
 from . import forward_solver, laplace, pt
 from . import workloads as W
 from .likelihood import LikelihoodEngine
@@ -219,16 +220,16 @@ def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if getattr(a, "use_dist", world > 1):
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=_pt.coll_device(dev))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     stats = eng.d_stats.cpu().numpy().reshape(-1, 8)
     # the slowest solve of a rank's last launch is what that rank's iteration waits for: one figure per rank
     steps_rank = [int(stats[:, 0].max())]
     if getattr(a, "use_dist", world > 1) and world > 1:
-        mine = torch.tensor(steps_rank, dtype=torch.int64, device=dev)
-        every = torch.zeros(world, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(every, mine)
+        mine = torch.tensor(steps_rank, dtype=torch.int64, device=_pt.coll_device(dev))
+        every = torch.zeros(world, dtype=torch.int64, device=_pt.coll_device(dev))
+        pt.all_gather_rows(every, mine)
         steps_rank = [int(v) for v in every.cpu()]
     line = {
         "metric": "mcmc_proposals_per_sec", "value": n_chains * a.steps / dt, "unit": "proposals/s", "n_gpus": world,

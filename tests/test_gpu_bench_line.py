@@ -51,3 +51,32 @@ def test_bench_line_through_a_one_rank_process_group():
         assert p["exchanges_timed"] >= 1 and all(ex[k] >= 0 for k in ("wait", "gather", "replay"))
     assert d["pt"]["64"]["cpu_baseline"]["kind"] == "port"
     assert d["accuracy"]["all_ok"] is True and max(d["accuracy"]["max_rel_err_per_decade_0_to_8"]) < 1e-6
+
+
+def test_two_rank_bench_line_rehearsed_on_one_gpu():
+    """The N > 1 control flow of bench.py -- rank 0's CPU baseline before its first GPU call while the other rank waits in
+    init_process_group, the weak-scaling region with its barriers and max-over-ranks, the rank-0-only legs (api, accuracy,
+    the 64-chain and one-GPU 512-chain ensembles) with every rank leaving them through one all-reduce, the 512-chain ensemble
+    block-partitioned over the ranks with its all-gather at every exchange, the assembly of the N > 1 line -- has never run on an
+    8-GPU node.  Here it runs as TWO ranks that share device 0 through a `gloo` group (MTRPL_REHEARSE_ONE_GPU=1: the numbers
+    mean nothing, the code path is the driver's): the line must come out, with the N > 1 fields in place."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MTRPL_REHEARSE_ONE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, cwd=REPO, timeout=1100, env=env)
+    if r.returncode != 0 and os.path.isdir(os.path.join(REPO, "gpurun_out")):
+        open(os.path.join(REPO, "gpurun_out", "bench_rehearsal.err"), "w").write(r.stderr)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["all_solves_ok"] is True
+    assert abs(d["value"] - 2 * 1024 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]  # whole-job rate: both ranks' solves
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0     # at N > 1 too (VERDICT r4 next 6a)
+    assert "roofline" in d and "api" in d and d["accuracy"]["all_ok"] is True
+    p = d["pt"]["512"]
+    assert p["n_gpus"] == 2 and p["scaling"] == "strong" and p["chains"] == 512 and p["ms_per_iteration"] > 0
+    assert 0 < p["collectives_per_iteration"] <= 0.2 and len(p["max_integrator_steps_per_rank"]) == 2
+    assert p["exchanges_timed"] >= 1 and p["exchange_ms"]["gather"] > 0
+    assert p["one_gpu_same_build"]["n_gpus"] == 1 and p["speedup_vs_one_gpu"] > 0
+    assert d["pt"]["64"]["n_gpus"] == 1 and d["pt"]["64"]["ms_per_iteration"] > 0
