@@ -39,3 +39,8 @@ def test_c_client_gets_the_same_traces(tmp_path):
     sig_c = raw[4 * 24:].view(np.float64).reshape(24, len(t))
     np.testing.assert_array_equal(st_c, status)
     np.testing.assert_array_equal(sig_c, sig)
+    # ... and through the pipelined host path: a pinned output buffer from mtrpl_host_alloc, three sub-launches of 8 solves
+    fout2 = str(tmp_path / "out2.bin")
+    r = subprocess.run([exe, fin, fout2, "8"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-500:])
+    np.testing.assert_array_equal(np.fromfile(fout2, dtype=np.uint8), raw)
