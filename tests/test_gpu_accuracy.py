@@ -13,9 +13,9 @@ accuracy claims.  DESIGN.md section 2 prints the measured table.
 
 The MEDIAN bounds are regression guards too, ten to a hundred times inside the contract.  Round 5 took the field components
 out of the controller's norms (they were setting the step size of most steps without being part of any signal: 9 % fewer
-steps) and tightened the internal rtol from 3e-9 to 2.4e-9 in exchange: the maxima came out as before or better (config 2
-decade 8: 6.2e-7 against 6.5e-7), the medians of decades 1 and 2 moved from 7e-9 / 1.7e-8 to 1.3e-8 / 2.4e-8 -- the error
-budget is spent more evenly -- and their guards from 1e-8 / 3e-8 to 2e-8 / 4e-8."""
+steps) and tightened the internal rtol from 3e-9 to 2e-9 in exchange: the maxima stayed where they were (config 2 decade 8:
+6.1e-7 against 6.5e-7; config-3 geometry 6.9e-7 against 6.3e-7), the medians of decades 1 and 2 moved from 7e-9 / 1.7e-8 to
+1.3e-8 / 2.6e-8 -- the error budget is spent more evenly -- and their guards from 1e-8 / 3e-8 to 2e-8 / 4e-8."""
 import os
 
 import numpy as np
