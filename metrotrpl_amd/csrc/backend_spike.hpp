@@ -41,6 +41,7 @@ struct SpikeBackendT {
     static constexpr bool kFieldInNorms = false;  // the field components in the controller's norms (solve_core.hpp)
     static constexpr bool kOrderRowInVgpr = false;
     static constexpr bool kBlocksSamples = false;
+    static constexpr bool kScalarPolicy = true;  // policy constants of a solve held in scalar registers (solve_core.hpp)
     static constexpr bool kParksSamples = true;  // out_sample() parks, out_flush() emits
     static constexpr int NI = W - 1;       // interfaces
     static constexpr int NIF = 4 * NI;     // scalar interface unknowns
@@ -199,11 +200,18 @@ struct SpikeBackendT {
         return m;
     }
     __device__ inline void out_begin(double *o, double min_y, double scale, double deep, double tail, double far, double post) { em.begin(o, min_y, scale, deep, tail, far, post); }
-    __device__ inline bool post() const { return em.post(); }
+    // (rmin and post_frac are non-negative floats in scalar registers, neither ever a NaN: compared as integers, on the scalar
+    // unit.  A vector compare takes ONE scalar operand, and the copy of the other was a register held for the whole solve.)
+    __device__ inline bool post() const { return !(__float_as_int(em.rmin) >= __float_as_int(em.post_frac)); }
     __device__ inline bool tail() const { return em.tail(); }
     __device__ inline bool far() const { return em.far(); }
     __device__ inline bool deep() const { return em.deep(); }
-    __device__ inline void out_first(double partial) { em.first(uniform(team_sum(partial)), p.dx, tid == 0); }
+    __device__ inline void out_first(double partial)
+    {
+        em.first(uniform(team_sum(partial)), p.dx, tid == 0);
+        em.inv_first = uniform(em.inv_first);  // (wave-uniform results of vector arithmetic: to scalar registers, kScalarPolicy)
+        em.post_frac = to_scalar(em.post_frac);
+    }
     // Output samples: the waves' partial sums of the samples one step crosses are parked in LDS and added up behind ONE
     // barrier when the step is through with them (out_flush) -- a step of the cruise phase crosses 2 to 25 samples.
     __device__ inline void out_sample(int k, double partial)
@@ -224,6 +232,8 @@ struct SpikeBackendT {
             for (int wv = 0; wv < W; ++wv) tot += q[wv];
             em.put(k0pend + n, tot, p.dx, tid == 0);
         }
+        em.rmin = uniform(em.rmin);
+        em.clamped = uniform(em.clamped);
         npend = 0;
         ppar ^= 1;  // (the other buffer until the next flush: a wave cannot be two flushes ahead)
     }
@@ -463,7 +473,14 @@ struct SpikeBackendT {
         done();
         double *qs_ = slot(wave, 0);  // 8 NI <= 24 doubles
         auto pub = [&](int wv, int which) { return xb + ((pb * W + wv) * 2 + which) * KX; };
-        V2 el[NI], ef[NI];  // E_j h'_j
+        // E_j h'_j of the last pair stays in registers, the earlier ones wait for the back substitution in this wave's own
+        // table (free until its last lines here fill it): lane m carries the unit right-hand side e_m, whose E_j h'_j is zero
+        // for every pair before its own (j < m / 4) -- row j has 4 (j + 1) lanes that are not, four doubles each, and the
+        // NI - 1 rows are 8 NI (NI - 1) doubles = the table's 4 NIF at NI = 3.  (An array indexed by the counter of a loop
+        // that is not unrolled lives in scratch memory; unrolled, these two loops spill 45 registers more.)
+        static_assert(8 * NI * (NI - 1) <= 4 * NIF, "parked rows fit this wave's table");
+        auto parked = [&](int j) { return tab + 8 * j * (j + 1) + 4 * lane; };
+        V2 el_last{0.0, 0.0}, ef_last{0.0, 0.0};
         {
             M2 Qp = mzero<double>(), Sp = mident<double>(), Wfp = mzero<double>();
 #pragma unroll 1
@@ -482,15 +499,19 @@ struct SpikeBackendT {
                 V2 hl_{(lane == 4 * j) ? 1.0 : 0.0, (lane == 4 * j + 1) ? 1.0 : 0.0};
                 const V2 hf_{(lane == 4 * j + 2) ? 1.0 : 0.0, (lane == 4 * j + 3) ? 1.0 : 0.0};
                 if (j > 0) {  // h'_j = h_j - L_j E_{j-1} h'_{j-1}: only the l-part changes, by Vl_j (E_{j-1} h'_{j-1})_l
-                    const V2 t = mvec(Vl, el[j - 1]);
+                    const V2 t = mvec(Vl, el_last);  // (still the previous pair's)
                     hl_ = V2{hl_.x - t.x, hl_.y - t.y};
                 }
                 // E h = [hl + Q S (Vf hl - hf) ; S (hf - Vf hl)]
                 const V2 vh = mvec(Vf, hl_);
                 const V2 sf = mvec(S, V2{hf_.x - vh.x, hf_.y - vh.y});
                 const V2 qsv = mvec(Q, sf);
-                el[j] = V2{hl_.x - qsv.x, hl_.y - qsv.y};
-                ef[j] = sf;
+                el_last = V2{hl_.x - qsv.x, hl_.y - qsv.y};
+                ef_last = sf;
+                if (j < NI - 1 && lane < 4 * (j + 1)) {
+                    double *q = parked(j);
+                    q[0] = el_last.x; q[1] = el_last.y; q[2] = ef_last.x; q[3] = ef_last.y;
+                }
                 Qp = Q;
                 Sp = S;
                 Wfp = m2_of(b + 4);  // W_first(j+1): acts on f_{j+2}
@@ -501,7 +522,13 @@ struct SpikeBackendT {
         V2 xl{0.0, 0.0}, xf{0.0, 0.0}, ufn{0.0, 0.0};
 #pragma unroll 1
         for (int j = NI - 1; j >= 0; --j) {
-            V2 ul = el[j], uf = ef[j];
+            V2 ul = el_last, uf = ef_last;
+            if (j < NI - 1) {
+                const bool mine = lane < 4 * (j + 1);
+                const double *q = mine ? parked(j) : tab;  // (a valid address in every lane)
+                ul = V2{mine ? q[0] : 0.0, mine ? q[1] : 0.0};
+                uf = V2{mine ? q[2] : 0.0, mine ? q[3] : 0.0};
+            }
             if (j < NI - 1) {
                 const M2 Q = m2_of(qs_ + 8 * j), S = m2_of(qs_ + 8 * j + 4), Wf = m2_of(pub(j + 1, 0) + 4);
                 const V2 sw = mvec(S, mvec(Wf, ufn));

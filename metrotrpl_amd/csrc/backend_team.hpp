@@ -28,6 +28,7 @@ struct TeamBackend {
     static constexpr bool kFieldInNorms = false;  // the field components in the controller's norms (solve_core.hpp)
     static constexpr bool kOrderRowInVgpr = false;
     static constexpr bool kBlocksSamples = false;
+    static constexpr bool kScalarPolicy = false;  // policy constants of a solve held in scalar registers (solve_core.hpp)
     static constexpr bool kParksSamples = false;
     static constexpr int LEVELS = 6 + (W >= 2 ? 1 : 0) + (W >= 4 ? 1 : 0);  // PCR levels over T rows
     static constexpr int NBLK = 5 + 2 * LEVELS;                              // elimination blocks per thread

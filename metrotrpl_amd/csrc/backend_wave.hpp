@@ -39,6 +39,7 @@ struct WaveBackendT {
     static constexpr bool kParksSamples = false;  // out_sample() parks, out_flush() emits
     static constexpr bool kOrderRowInVgpr = ROWV;  // the order table's row by v_readlane (solve_core.hpp: OrderRow): the one-per-SIMD kernel
     static constexpr bool kBlocksSamples = true;  // the samples leave in blocks of 64: integrate() calls out_finish() at the end
+    static constexpr bool kScalarPolicy = false;  // policy constants of a solve held in scalar registers (solve_core.hpp)
 
     Par p;
     int L, lane;

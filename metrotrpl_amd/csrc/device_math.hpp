@@ -49,6 +49,18 @@ template <class T> __device__ inline T uniform(T v)
     return u.d;
 }
 __device__ inline int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// ... and when the compiler can see for itself that v is uniform it drops the readfirstlane and leaves v in the vector register
+// its arithmetic produced it in (floating point is on the vector unit only): the move as an instruction it cannot see through.
+// The wait states are part of it: a scalar register written by a vector instruction may be read by the next vector
+// instruction but one at the earliest (two wait states on this ISA), and the value read may come from the transcendental
+// unit (one); the compiler inserts such s_nops around its own instructions, not around the inside of an asm statement --
+// without them the spill of this register, two instructions on, stored whatever the register held before.
+__device__ inline float to_scalar(float v)
+{
+    int r;
+    asm("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(r) : "v"(v));
+    return __int_as_float(r);
+}
 
 // value of lane `src` as a wave-uniform scalar
 template <class T> __device__ inline T lane_value(T v, int src)

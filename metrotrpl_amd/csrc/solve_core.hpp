@@ -444,13 +444,20 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
     // and tolerances are far inside the fp32 range; the absolute terms are kept above its smallest normal number,
     // so that a caller's ATOL = 0 (or 1e-45) next to a component that has gone to zero gives a finite weight and
     // not 1/0 (the reference's LSODA integrates such a case).
-    const ctl rtol_f = (ctl)rtol, rtol_E_f = (ctl)rtol_E, atol_f = fmaxf((ctl)atol, 1e-37f), atol_E_f = fmaxf((ctl)atol_E, 1e-37f);
-    const real early_until = (nt > 1) ? (real)(tune.early_frac * ts[1]) : (real)0;
+    // (a backend short of vector registers keeps these wave-uniform values in scalar ones: BK::kScalarPolicy.  They come out
+    // of floating-point arithmetic, which this ISA has on the vector unit only, so the compiler leaves them where they were
+    // computed -- and, in a kernel that spills, spills them.)
+    auto sc = [](auto x) {
+        if constexpr (BK::kScalarPolicy) return uniform(x);
+        else return x;
+    };
+    const ctl rtol_f = sc((ctl)rtol), rtol_E_f = sc((ctl)rtol_E), atol_f = sc(fmaxf((ctl)atol, 1e-37f)), atol_E_f = sc(fmaxf((ctl)atol_E, 1e-37f));
+    const real early_until = sc((nt > 1) ? (real)(tune.early_frac * ts[1]) : (real)0);
     const ctl early_mul = (ctl)(1.0 / fmax(tune.early_factor, 1.0));  // norms of an early step are scaled by this
-    const ctl tail_mul = (ctl)(1.0 / tune.tail_factor), far_mul = (ctl)(1.0 / tune.far_factor), deep_mul = (ctl)(1.0 / (tune.far_factor * tune.deep_factor)), amp_mul = (ctl)amp_mul_d;
-    const ctl newton_tol = (tune.newton_tol > 0.0)
+    const ctl tail_mul = (ctl)(1.0 / tune.tail_factor), far_mul = (ctl)(1.0 / tune.far_factor), deep_mul = (ctl)(1.0 / (tune.far_factor * tune.deep_factor)), amp_mul = sc((ctl)amp_mul_d);
+    const ctl newton_tol = sc((tune.newton_tol > 0.0)
                                ? (ctl)tune.newton_tol
-                               : (ctl)fmax(10.0 * 2.220446049250313e-16 / (double)rtol, fmin(0.03, sqrt((double)rtol)));
+                               : (ctl)fmax(10.0 * 2.220446049250313e-16 / (double)rtol, fmin(0.03, sqrt((double)rtol))));
 
     const bool goal = tune.shape_factor > 1.0;  // goal-oriented error test on
     int n_steps = 0, n_rhs = 0, n_fac = 0, n_bad = 0;  // n_bad: rejected steps | Newton failures << 16
@@ -851,7 +858,7 @@ __device__ inline void integrate(BK &bk, const mtrpl_solve_desc &ds, const doubl
                 real fac = (real)facf;
                 // max_step guards LSODA against stepping over structure; once the signal is down in the rounding noise
                 // of N P - n0 p0 (hmax_deep, 11 decades by default) there is none left and the error test alone decides
-                if (h * fac > hmax && !bk.deep()) fac = hmax * frcp(h);
+                if (tune.honor_hmax && h * fac > hmax && !bk.deep()) fac = hmax * frcp(h);
                 if (dorder == 0 && fac >= (real)0.9 && fac < (real)tune.nq_deadband_hi) {
                     n_equal = order - 2;  // keep h and the factors; test again three steps on
                 } else {

@@ -346,3 +346,21 @@ def test_spike_linear_solver_against_dense_solves():
     # the SPIKE coupling costs no accuracy: two and four waves are no worse than what one wave does at nx <= 128 by more
     # than the finer grid's conditioning (dx^-2)
     assert worst[512][0] < 100 * max(worst[128][0], 1e-6)
+
+
+@pytest.mark.parametrize("nx", [512, 256])  # four waves per solve | two
+def test_config5_batch_every_solve_through_and_repeatable(nx):
+    """The whole config-5 batch of bench.py (128 seeded states x two thicknesses x TRPL / TRTS, all resident at once): every
+    solve ends with status 0 and a second run returns the same bytes and the same step counts.  (A scalar register read one
+    instruction too early -- an ISA wait state missing behind a hand-written instruction -- once made a few dozen of these 512
+    solves fail, a different few dozen each run, with every parity test of sixteen traces green.)"""
+    from metrotrpl_amd import batch, workloads as W
+    c = W.config5(128, nx)
+    runs = [batch.solve_batch(c["states"], W.indexes(), W.units(), c["iniPar"], c["thickness"], c["nx"], c["tSteps"], hmax=c["hmax"],
+                              meas=c["meas"], model=c["model"], ini_mode=c["ini_mode"], return_stats=True) for _ in range(2)]
+    for sig, status, stats in runs:
+        assert np.all(status == 0), np.unique(status, return_counts=True)
+        assert np.all(np.isfinite(sig)) and np.all(sig > 0)
+        assert stats[:, 5].max() <= 3, stats[:, 5].max()  # Newton failures of a solve: a handful at most
+    assert np.array_equal(runs[0][0], runs[1][0])
+    assert np.array_equal(runs[0][2][:, :7], runs[1][2][:, :7])  # (column 7 is the solve's residency in clock ticks)
