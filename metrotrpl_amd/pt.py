@@ -333,7 +333,7 @@ class PTEnsemble:
     _frozen = False  # gc.freeze() has been called by an ensemble of this process (advance)
 
     def __init__(self, states, temperatures, evaluator, rank=0, world=1, seed=235817049752375780, group=None,
-                 rng_mode="stream", streams=None, device_decisions=False, gc_freeze=False):
+                 rng_mode="stream", streams=None, device_decisions=False, gc_freeze=False, regroup_by_cost=False):
         if rng_mode not in ("stream", "counter"):
             raise ValueError("rng_mode must be 'stream' or 'counter'")
         self.states = np.array(states, dtype=np.float64)
@@ -372,6 +372,13 @@ class PTEnsemble:
         self.chain_cost = np.zeros(self.n)  # what the evaluator said a chain's last evaluation cost (own rows; 0 = unknown)
         self.device_decisions = bool(device_decisions)
         self.gc_freeze = bool(gc_freeze)
+        # Latency-bound ensembles (a launch of every group fits the device at once): at every replica exchange the own
+        # chains are dealt to the groups again BY COST -- the most expensive chains to the group that starts first -- so
+        # that one group carries the slow chains and the others finish early, instead of every group waiting for a slow
+        # chain of its own in every launch (`_pipelined`; needs evaluators with `row_cost`).  A chain's walk does not
+        # depend on the group it is in (counter mode).  Throughput-bound ensembles want groups of EQUAL cost: off.
+        self.regroup_by_cost = bool(regroup_by_cost)
+        self.pipe_own = {}  # group -> the own chains its pipe walks in the current stretch (default: own[g])
         self.n_pipelined = 0  # launches decided on the device so far
         # host seconds of the replica exchanges so far: waiting for the groups' last launches | the all-gather and its
         # copy to the host | swap replay, permutation and the upload of the own rows; and how many there were
@@ -662,8 +669,14 @@ class PTEnsemble:
         # until then): its proposals are made for all the groups at once, and a group's pipe is built right before its
         # first launch goes out, not before everybody's.
         first = None
+        self.pipe_own = {}
         if len(todo) > 1 and len({self.git[g] for g, _ in todo}) == 1:
             allsel = np.concatenate([self.own[g] for g, _ in todo])
+            if (self.regroup_by_cost and len(todo) == self.groups and len({n for _, n in todo}) == 1
+                    and np.any(self.chain_cost[allsel] > 0)):
+                by_cost = allsel[np.argsort(-self.chain_cost[allsel], kind="stable")]
+                cuts = np.cumsum([0] + [self.own[g].shape[0] for g, _ in todo])  # (the groups keep their sizes)
+                self.pipe_own = {g: by_cost[a:b] for (g, _), a, b in zip(todo, cuts[:-1], cuts[1:])}
             if allsel.shape[0]:
                 it = self.git[todo[0][0]]
                 xs, Ts = self.states[allsel], self.T[allsel]
@@ -766,7 +779,7 @@ class _DecidePipe:
         self.G = 3 if depth == 2 else 1  # proposals per chain and launch
         self.ev = ens.evaluators[g]
         self.stream = ens.streams[g]
-        self.sel = ens.own[g]
+        self.sel = ens.pipe_own.get(g, ens.own[g])
         if hasattr(self.ev, "row_cost") and self.sel.shape[0]:
             # the chains that were expensive in the last launch go first: launches of two groups share the device, and
             # what has to wait for a SIMD should be the cheapest solves (the hardware starts workgroups in index order)

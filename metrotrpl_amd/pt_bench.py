@@ -63,7 +63,7 @@ def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=Tr
     T = ens0["temperatures"]
     d_T = torch.from_numpy(np.ascontiguousarray(T)).to(dev)
 
-    def make(_):
+    def make(g_):
         eng = LikelihoodEngine(W.indexes(), W.units(), W.STAUB_LENGTHS, nx, ["TRPL"] * 6, [times] * 6, vals, uncs,
                                {"TRPL": 1.0}, np.array(W.STAUB_FLUENCES), ini_mode="fluence", irf_tables=irf_tables,
                                irf_convolution=[745] * 6, device=local, ctx=ctx, sort_by_cost=sort_by_cost, parts=parts,
@@ -81,9 +81,23 @@ def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=Tr
                 eng.prof["launch"] = eng.prof.get("launch", 0.0) + time.perf_counter() - t1
             return tab
 
+        # The latency-bound ensemble (packed_order "chains": three groups' launches in flight) wants 64 x 6 x 3 = 1152 SIMDs
+        # of 1024: whatever is launched last waits for one.  Its chains are dealt to the groups by cost at every replica
+        # exchange (pt.PTEnsemble.regroup_by_cost) and the last group -- the cheapest chains -- runs two solves per SIMD:
+        # 396 + 378 + 189 SIMDs, nobody waits, and the solves that take 1.4x as long are the ones with time to spare.
+        dealt = packed_order == "chains" and groups > 2 and os.environ.get("MTRPL_PT_NO_REGROUP") != "1"
+        two = dealt and g_ == groups - 1
+
         def launch_packed(d_descs, n_solves, temps):
             eng.use_packed(d_descs, n_solves)
-            return eng.launch(d_T, len(temps)).view(-1, eng.M, len(temps)).sum(dim=1)
+            if two:  # (the library picks the kernel build when the launch is issued: a host-side switch around the call)
+                keep = ctx.get_option("two_per_simd_min_batch")
+                ctx.set_option("two_per_simd_min_batch", 1)
+            try:
+                return eng.launch(d_T, len(temps)).view(-1, eng.M, len(temps)).sum(dim=1)
+            finally:
+                if two:
+                    ctx.set_option("two_per_simd_min_batch", keep)
         evaluator.pack_rows, evaluator.launch_packed, evaluator.packable = eng.pack_rows, launch_packed, eng.packable()
 
         # pt._DecidePipe: the two decisions of a launch and the pick of the next launch's descriptors, one kernel each
@@ -103,15 +117,15 @@ def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=Tr
             return eng.d_stats[:8 * n_rows * eng.M].view(n_rows, eng.M, 8)[:, :, 0].max(dim=1).values.cpu().numpy()
         # the order of a packed launch's solves: big launches solve by solve (the engine's measured-cost order and
         # stream split, fixed per stretch between two exchanges), small ones chain by chain (pt._DecidePipe)
-        # (chain by chain -- evaluator.row_cost = row_cost -- measured nothing on the three-group 64-chain ensemble:
-        # 2.37 ms per iteration with it, without it and solve by solve; it costs a blocking read per group and stretch)
+        # (ordering alone measured nothing on the three-group 64-chain ensemble: 2.37 ms per iteration chain by chain, solve
+        # by solve and as given; what `row_cost` is for there is the deal of the chains to the groups, above)
         if os.environ.get("MTRPL_PT_NO_ORDER") != "1":
             if packed_order == "solves":
                 # every group's launches, whatever their size (three groups of a 512-chain ensemble are 1026,
                 # 1026 and 1020 solves -- a threshold of 1024 ordered two of them; at N > 1 none)
                 eng.packed_sort_min = 0
                 evaluator.plan_packed = eng.plan_packed
-            elif os.environ.get("MTRPL_PT_CHAIN_ORDER") == "1":
+            elif dealt:
                 evaluator.row_cost = row_cost
         return eng, evaluator
     made = [make(g) for g in range(max(1, groups))]
@@ -134,7 +148,8 @@ def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=Tr
 def run(a, rank, world, local, dev, cpu_baseline_fn=None):
     """One `bench.py --workload pt` line (also the `pt` legs of the default line).  Experiment switches, all off by default
     (environment): MTRPL_NO_SORT=1 / MTRPL_PARTS=n (the engine's measured-cost order / stream split), MTRPL_PT_NO_ORDER=1
-    (packed launches as given), MTRPL_PT_CHAIN_ORDER=1 (small packed launches chain by chain, most expensive first),
+    (packed launches as given), MTRPL_PT_NO_REGROUP=1 (the latency-bound ensemble keeps its interleaved chain groups, one
+    solve per SIMD in all of them),
     MTRPL_LL_WAVE=0|1|2|4 (waves per likelihood block where several throughput-bound groups share the device; 0 = twelve),
     MTRPL_PT_PROF=1 (host milliseconds per phase into config.host_ms)."""
     import torch
@@ -195,7 +210,8 @@ def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups
     local_only = world == 1 and not getattr(a, "use_dist", False)
     ens = pt.PTEnsemble(ens0["chain_states"], T, S["evaluators"] if groups > 1 else S["evaluator"], rank=rank,
                         world=world, rng_mode="counter", streams=S["streams"], group=pt.LOCAL_ONLY if local_only else None,
-                        device_decisions=decide == "device", gc_freeze=True)  # (the benchmark owns its process)
+                        device_decisions=decide == "device", gc_freeze=True,  # (the benchmark owns its process)
+                        regroup_by_cost=small and groups > 2 and os.environ.get("MTRPL_PT_NO_REGROUP") != "1")
     ens.initialise()
     temper_freq = 10
     ens.advance(proposer, a.warmup, temper_freq, prefetch)

@@ -139,7 +139,7 @@ class _PackedToy:
 
 
 def _run_counter(n_chains, iters, prefetch, rank=0, world=1, temper_freq=4, groups=1, device_decisions=False,
-                 own_order=False):
+                 own_order=False, regroup=False):
     ens0 = W.pt_ensemble(n_chains)
     calls = []
 
@@ -150,7 +150,7 @@ def _run_counter(n_chains, iters, prefetch, rank=0, world=1, temper_freq=4, grou
         ev = [_PackedToy(calls, own_order) for _ in range(groups)]
         ev = ev[0] if groups == 1 else ev
     e = pt.PTEnsemble(ens0["chain_states"], ens0["temperatures"], ev if groups == 1 or device_decisions else [ev] * groups, rank=rank,
-                      world=world, rng_mode="counter", device_decisions=device_decisions)
+                      world=world, rng_mode="counter", device_decisions=device_decisions, regroup_by_cost=regroup)
     e.initialise()
     n_acc = e.advance(_proposer(), iters, temper_freq, prefetch=prefetch)
     return e, n_acc, calls
@@ -255,6 +255,39 @@ def test_an_evaluator_that_cannot_pack_walks_the_host_path():
     assert acc == acc_s and e.n_pipelined == 0 and not any(isinstance(c, tuple) for c in calls)
     np.testing.assert_array_equal(e.states, seq.states)
     np.testing.assert_array_equal(e.table, seq.table)
+
+
+@pytest.mark.parametrize("groups,n_chains,prefetch", [(2, 8, True), (3, 8, True), (3, 11, False)])
+def test_chain_groups_dealt_by_cost_walk_the_same_chain(groups, n_chains, prefetch):
+    """`regroup_by_cost`: at every replica exchange the chains are dealt to the groups again, the most expensive ones (what
+    the evaluators' `row_cost` said of the stretch before) to the group that starts first.  Which group evaluates a chain is
+    no part of its walk: the one-iteration-at-a-time chain, bit for bit -- and the groups did change hands."""
+    iters, temper_freq = 26, 6
+    seq, acc_s, _ = _run_counter(n_chains, iters, False, temper_freq=temper_freq)
+    seen = []
+    keep = pt._DecidePipe.__init__
+
+    def spy(self, ens, g, *a, **k):
+        keep(self, ens, g, *a, **k)
+        seen.append((g, tuple(sorted(self.sel.tolist()))))
+    pt._DecidePipe.__init__ = spy
+    try:
+        dev, acc_d, _ = _run_counter(n_chains, iters, prefetch, temper_freq=temper_freq, groups=groups, device_decisions=True,
+                                     regroup=True)
+    finally:
+        pt._DecidePipe.__init__ = keep
+    assert acc_d == acc_s and dev.it == iters and dev.git == [iters] * groups
+    np.testing.assert_array_equal(dev.states, seq.states)
+    np.testing.assert_array_equal(dev.logll, seq.logll)
+    np.testing.assert_array_equal(dev.table, seq.table)
+    np.testing.assert_array_equal(dev.acc_count, seq.acc_count)
+    np.testing.assert_array_equal(dev.swap_accepts, seq.swap_accepts)
+    static = {g: tuple(range(g, n_chains, groups)) for g in range(groups)}
+    stretches = [seen[k:k + groups] for k in range(0, len(seen), groups)]
+    assert all(sorted(c for _, m in st for c in m) == list(range(n_chains)) for st in stretches)  # every chain, once
+    assert all(len(m) == len(static[g]) for st in stretches for g, m in st)  # the groups keep their sizes
+    assert [m for g, m in stretches[0]] == [static[g] for g in range(groups)]  # no cost known yet: as constructed
+    assert any(m != static[g] for st in stretches[1:] for g, m in st)
 
 
 def _prefetch_worker(rank, world, port, n_chains, iters, groups, q, device_decisions=False):
