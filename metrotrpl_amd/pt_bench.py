@@ -51,9 +51,11 @@ def synthetic_data(irf_tables, nx, times):
 
 
 def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=True, split_min=2048, sort_min=1024,
-          ctx=None, force_min_y=False, groups=1, packed_order="chains"):
+          ctx=None, force_min_y=False, groups=1, packed_order="chains", dealt=False):
     """The config-3/4 problem on one rank: engine(s), ladder, evaluator(s) and proposer.  groups > 1: one
-    engine, evaluator and HIP stream per chain group of pt.PTEnsemble."""
+    engine, evaluator and HIP stream per chain group of pt.PTEnsemble.  `dealt`: evaluators for an ensemble that deals its
+    chains to the groups by cost (`PTEnsemble(regroup_by_cost=True)`: the two go together) -- they report what a chain cost
+    and the last group runs two solves per SIMD."""
     import torch
     times = W.default_times()
     ctx = ctx or L.default_context(local)
@@ -85,7 +87,6 @@ def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=Tr
         # of 1024: whatever is launched last waits for one.  Its chains are dealt to the groups by cost at every replica
         # exchange (pt.PTEnsemble.regroup_by_cost) and the last group -- the cheapest chains -- runs two solves per SIMD:
         # 396 + 378 + 189 SIMDs, nobody waits, and the solves that take 1.4x as long are the ones with time to spare.
-        dealt = packed_order == "chains" and groups > 2 and os.environ.get("MTRPL_PT_NO_REGROUP") != "1"
         two = dealt and g_ == groups - 1
 
         def launch_packed(d_descs, n_solves, temps):
@@ -199,9 +200,10 @@ def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups
     # solves) chain by chain, the throughput-bound launches solve by solve, both by the integrator's cost in the
     # previous launch
     small = prefetch and groups > 1
+    dealt = small and groups > 2 and os.environ.get("MTRPL_PT_NO_REGROUP") != "1"
     S = setup(n_chains, dev, local, sort_by_cost=os.environ.get("MTRPL_NO_SORT") != "1",
               parts=int(os.environ.get("MTRPL_PARTS", "2" if groups == 1 else "1")), groups=groups,
-              packed_order="chains" if small else "solves")
+              packed_order="chains" if small else "solves", dealt=dealt)
     eng, ens0, T, proposer = S["eng"], S["ens0"], S["T"], S["proposer"]
     # history-free draws (pt.PTEnsemble "counter" mode): the chain walked does not depend on N, on prefetching
     # or on the chain groups
@@ -211,7 +213,7 @@ def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups
     ens = pt.PTEnsemble(ens0["chain_states"], T, S["evaluators"] if groups > 1 else S["evaluator"], rank=rank,
                         world=world, rng_mode="counter", streams=S["streams"], group=pt.LOCAL_ONLY if local_only else None,
                         device_decisions=decide == "device", gc_freeze=True,  # (the benchmark owns its process)
-                        regroup_by_cost=small and groups > 2 and os.environ.get("MTRPL_PT_NO_REGROUP") != "1")
+                        regroup_by_cost=dealt)
     ens.initialise()
     temper_freq = 10
     ens.advance(proposer, a.warmup, temper_freq, prefetch)

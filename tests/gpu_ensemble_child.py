@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--kernel-variant", type=int, default=0)
     ap.add_argument("--device-decisions", type=int, default=0)
     ap.add_argument("--packed-order", default="chains")
+    ap.add_argument("--dealt", type=int, default=0)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     import torch
@@ -42,9 +43,11 @@ def main():
     L.default_context(0).set_option("kernel_variant", a.kernel_variant)
     irf_raw = np.load(os.path.join(REPO, "tests", "golden", "irf.npz"))["irf745_raw"]
     S = pt_bench.setup(a.chains, dev, 0, irf_raw=irf_raw, parts=a.parts, sort_by_cost=bool(a.sort), split_min=0,
-                       sort_min=0, force_min_y=bool(a.force_min_y), groups=a.groups, packed_order=a.packed_order)
+                       sort_min=0, force_min_y=bool(a.force_min_y), groups=a.groups, packed_order=a.packed_order,
+                       dealt=bool(a.dealt))
     ens = pt.PTEnsemble(S["ens0"]["chain_states"], S["T"], S["evaluators"] if a.groups > 1 else S["evaluator"], rank=0,
-                        world=1, rng_mode=a.rng_mode, streams=S["streams"], device_decisions=bool(a.device_decisions))
+                        world=1, rng_mode=a.rng_mode, streams=S["streams"], device_decisions=bool(a.device_decisions),
+                        regroup_by_cost=bool(a.dealt))
     ens.initialise()
     table0 = ens.table.copy()
     n_parts = len(S["eng"]._cuts) - 1
@@ -70,7 +73,8 @@ def main():
              swap_attempts=ens.swap_attempts, swap_accepts=ens.swap_accepts, T=S["T"], times=S["times"],
              vals=np.array(S["vals"]), uncs=np.array(S["uncs"]), n_parts=n_parts, swaps=swaps, backend=np.array(backend),
              ordered=np.array(S["eng"]._order is not None), calls=np.array(calls), n_acc=n_acc, n_collectives=ens.n_collectives,
-             n_pipelined=ens.n_pipelined)
+             n_pipelined=ens.n_pipelined, pipe_own=np.concatenate([ens.pipe_own[g] for g in sorted(ens.pipe_own)] or [np.zeros(0)]),
+             chain_cost=ens.chain_cost)
     if a.dist:
         dist.destroy_process_group()
 

@@ -116,6 +116,16 @@ def test_prefetched_ensemble_walks_the_same_chain(tmp_path):
     assert int(dd2["n_pipelined"]) == 6 and list(dd2["calls"]) == []
     for key in ("states", "logll", "table", "swap_attempts", "swap_accepts", "n_acc"):
         np.testing.assert_array_equal(ref6[key], dd2[key], err_msg=key)
+    # ... and three groups whose chains are dealt again by cost at every replica exchange, the last group two solves per SIMD
+    # (the latency-bound form of bench.py's 64-chain ensemble): the second stretch of six iterations runs on dealt groups
+    dealt = _child(tmp_path, "dealt", dist=0, parts=1, sort=0, rng_mode="counter", prefetch=1, iters=12, temper_freq=6,
+                   groups=3, device_decisions=1, dealt=1)
+    assert int(dealt["n_pipelined"]) == 18 and list(dealt["calls"]) == []
+    for key in ("states", "logll", "table", "swap_attempts", "swap_accepts", "n_acc"):
+        np.testing.assert_array_equal(ref6[key], dealt[key], err_msg=key)
+    own, cost = dealt["pipe_own"].astype(int), dealt["chain_cost"]
+    assert sorted(own.tolist()) == list(range(64)) and np.all(cost > 0)
+    assert not np.array_equal(own, np.concatenate([np.arange(g, 64, 3) for g in range(3)]))  # not the interleaved groups
     # the fp64-block kernel walks the same chain: the same decisions, log-likelihoods to 1e-7
     f64 = _child(tmp_path, "f64", dist=0, parts=1, sort=1, rng_mode="counter", prefetch=1, iters=12, temper_freq=4,
                  kernel_variant=2)
