@@ -91,7 +91,11 @@ class LikelihoodEngine:
             self.d_sig = torch.zeros(tot, dtype=torch.float64, device=self.dev)
             self.d_status = torch.zeros(n_solves, dtype=torch.int32, device=self.dev)
             self.d_stats = torch.zeros(n_solves * 8, dtype=torch.int32, device=self.dev)
-        self.d_ll = torch.zeros(n_solves * nT, dtype=torch.float64, device=self.dev)
+        # (the likelihood kernel writes every entry of the table -- NaN for a descriptor it refuses, -inf for a failed trace --
+        # so the buffer is neither cleared nor made anew per launch: a 4 MB fill kernel took its turn among the solves of
+        # three chain groups, half a millisecond of every launch cycle of the 512-chain ensemble)
+        if getattr(self, "d_ll", None) is None or self.d_ll.shape[0] != n_solves * nT:
+            self.d_ll = torch.empty(n_solves * nT, dtype=torch.float64, device=self.dev)
 
     def _template(self, Cn):
         """Everything in the descriptors of C chains x M measurements (chain-major) that does not depend on the
