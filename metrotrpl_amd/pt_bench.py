@@ -51,11 +51,11 @@ def synthetic_data(irf_tables, nx, times):
 
 
 def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=True, split_min=2048, sort_min=1024,
-          ctx=None, force_min_y=False, groups=1, packed_order="chains", dealt=False):
+          ctx=None, force_min_y=False, groups=1, packed_order="chains", dealt=None):
     """The config-3/4 problem on one rank: engine(s), ladder, evaluator(s) and proposer.  groups > 1: one
-    engine, evaluator and HIP stream per chain group of pt.PTEnsemble.  `dealt`: evaluators for an ensemble that deals its
-    chains to the groups by cost (`PTEnsemble(regroup_by_cost=True)`: the two go together) -- they report what a chain cost
-    and the last group runs two solves per SIMD."""
+    engine, evaluator and HIP stream per chain group of pt.PTEnsemble.  `dealt` = k: evaluators for an ensemble that deals its
+    chains to the groups by cost (`PTEnsemble(regroup_by_cost=True)`: the two go together) -- they report what a chain cost,
+    the first k groups (the expensive chains) run one solve per SIMD and the others two."""
     import torch
     times = W.default_times()
     ctx = ctx or L.default_context(local)
@@ -83,21 +83,22 @@ def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=Tr
                 eng.prof["launch"] = eng.prof.get("launch", 0.0) + time.perf_counter() - t1
             return tab
 
-        # The latency-bound ensemble (packed_order "chains": three groups' launches in flight) wants 64 x 6 x 3 = 1152 SIMDs
-        # of 1024: whatever is launched last waits for one.  Its chains are dealt to the groups by cost at every replica
-        # exchange (pt.PTEnsemble.regroup_by_cost) and the last group -- the cheapest chains -- runs two solves per SIMD:
-        # 396 + 378 + 189 SIMDs, nobody waits, and the solves that take 1.4x as long are the ones with time to spare.
-        two = dealt and g_ == groups - 1
+        # A latency-bound ensemble -- the launches of all its groups fit the device at once, if some of them run two solves
+        # per SIMD -- has its chains dealt to the groups by cost at every replica exchange (pt.PTEnsemble.regroup_by_cost),
+        # the first `dealt` groups (the expensive chains) run one solve per SIMD and the others two: nobody waits for a SIMD,
+        # and the solves that take 1.4x as long are the ones with time to spare.  64 chains, two iterations per launch:
+        # 396 + 378 + 189 of 1024 SIMDs (all one per SIMD: 1152); 256 chains, one iteration: 516 + 255 + 255.
+        per_simd = None if dealt is None else (1 if g_ < dealt else 2)
 
         def launch_packed(d_descs, n_solves, temps):
             eng.use_packed(d_descs, n_solves)
-            if two:  # (the library picks the kernel build when the launch is issued: a host-side switch around the call)
+            if per_simd:  # (the library picks the kernel build when the launch is issued: a host-side switch around the call)
                 keep = ctx.get_option("two_per_simd_min_batch")
-                ctx.set_option("two_per_simd_min_batch", 1)
+                ctx.set_option("two_per_simd_min_batch", 1 if per_simd == 2 else 1 << 30)
             try:
                 return eng.launch(d_T, len(temps)).view(-1, eng.M, len(temps)).sum(dim=1)
             finally:
-                if two:
+                if per_simd:
                     ctx.set_option("two_per_simd_min_batch", keep)
         evaluator.pack_rows, evaluator.launch_packed, evaluator.packable = eng.pack_rows, launch_packed, eng.packable()
 
@@ -126,7 +127,7 @@ def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=Tr
                 # 1026 and 1020 solves -- a threshold of 1024 ordered two of them; at N > 1 none)
                 eng.packed_sort_min = 0
                 evaluator.plan_packed = eng.plan_packed
-            elif dealt:
+            elif dealt is not None:
                 evaluator.row_cost = row_cost
         return eng, evaluator
     made = [make(g) for g in range(max(1, groups))]
@@ -149,8 +150,8 @@ def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=Tr
 def run(a, rank, world, local, dev, cpu_baseline_fn=None):
     """One `bench.py --workload pt` line (also the `pt` legs of the default line).  Experiment switches, all off by default
     (environment): MTRPL_NO_SORT=1 / MTRPL_PARTS=n (the engine's measured-cost order / stream split), MTRPL_PT_NO_ORDER=1
-    (packed launches as given), MTRPL_PT_NO_REGROUP=1 (the latency-bound ensemble keeps its interleaved chain groups, one
-    solve per SIMD in all of them),
+    (packed launches as given), MTRPL_PT_NO_REGROUP=1 (a latency-bound ensemble keeps its interleaved chain groups and one
+    kernel build for all of them), MTRPL_PT_ONE_GROUPS=k (how many of its groups run one solve per SIMD),
     MTRPL_LL_WAVE=0|1|2|4 (waves per likelihood block where several throughput-bound groups share the device; 0 = twelve),
     MTRPL_PT_PROF=1 (host milliseconds per phase into config.host_ms)."""
     import torch
@@ -170,6 +171,20 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
     # behind the launch of the other (prefetching), one otherwise.
     decide = getattr(a, "decide", "device")
     groups = int(getattr(a, "groups", 0)) or (3 if decide == "device" else (2 if prefetch else 1))
+    # Latency-bound or throughput-bound?  g solves per group launch, all groups in flight: with k groups one solve per SIMD
+    # and the others two they need k g + (groups - k) g / 2 SIMDs.  k = the most that fits (64 chains, prefetching: g = 396,
+    # k = 2; 256 chains, one iteration per launch: g = 516, k = 1); nothing fits even with every solve doubled up (512 chains:
+    # g = 1026): throughput-bound, the groups stay as they are and every launch runs two per SIMD.  A latency-bound ensemble
+    # deals its chains to the groups by cost (setup(dealt = k), pt.PTEnsemble.regroup_by_cost).
+    g_solves = -(-(hi - lo) // groups) * 6 * (3 if prefetch else 1)
+    k_one = max(0, min(groups, int(2 * slots * 1.02 / max(g_solves, 1) - groups)))  # (a dozen solves over is still a fit)
+    if prefetch and groups > 1 and k_one == 0:
+        k_one = 1  # (128 chains, prefetching: 2304 solves in flight, more than fit either way; measured: k = 1 2.86 ms per
+        #            iteration, k = 2 2.92, interleaved groups one per SIMD 3.00)
+    k_one = int(os.environ.get("MTRPL_PT_ONE_GROUPS", k_one))
+    fits = groups * g_solves <= 2 * slots * 1.15
+    dealt = k_one if (groups > 2 and decide == "device" and fits and 0 < k_one < groups
+                      and os.environ.get("MTRPL_PT_NO_REGROUP") != "1") else None
     ctx = L.default_context(local)
     restore = {}
 
@@ -177,22 +192,24 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
         restore.setdefault(key, ctx.get_option(key))
         ctx.set_option(key, value)
     if groups > 1 and not prefetch:
-        # several throughput-bound groups share the device.  Every launch, whatever its size, runs two solves per SIMD;
-        # and a group's likelihood launch has to find room among the other groups' queued solves: blocks of one wave
-        # do, blocks of twelve wait until that queue has drained (include/metrotrpl_amd.h, loglik_wave_blocks)
+        # several groups, one iteration per launch.  Throughput-bound: every launch, whatever its size, runs two solves per
+        # SIMD, and a group's likelihood launch has to find room among the other groups' queued solves -- blocks of one
+        # wave do, blocks of twelve wait until that queue has drained (include/metrotrpl_amd.h, loglik_wave_blocks).
+        # Latency-bound (dealt): each group's evaluator says which build its launches use, and there is room for the
+        # twelve-wave blocks (256 chains: 4.24 ms per iteration against 4.50 with blocks of one wave, 4.84 not dealt)
         set_option("two_per_simd_min_batch", 1)
-        set_option("loglik_wave_blocks", float(os.environ.get("MTRPL_LL_WAVE", "1")))
+        set_option("loglik_wave_blocks", float(os.environ.get("MTRPL_LL_WAVE", "0" if dealt is not None else "1")))
     for kv in getattr(a, "opt", []) or []:
         k_, v_ = kv.split("=")
         set_option(k_, float(v_))
     try:
-        return _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups, decide)
+        return _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups, decide, dealt)
     finally:
         for k_, v_ in restore.items():  # the context is the process's default one: other bench legs use it too
             ctx.set_option(k_, v_)
 
 
-def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups, decide):
+def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups, decide, dealt):
     import torch
     import torch.distributed as dist
     # the order the solves of a launch are issued in: the small launches of the prefetching ensemble (launches of a few
@@ -200,10 +217,9 @@ def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups
     # solves) chain by chain, the throughput-bound launches solve by solve, both by the integrator's cost in the
     # previous launch
     small = prefetch and groups > 1
-    dealt = small and groups > 2 and os.environ.get("MTRPL_PT_NO_REGROUP") != "1"
     S = setup(n_chains, dev, local, sort_by_cost=os.environ.get("MTRPL_NO_SORT") != "1",
               parts=int(os.environ.get("MTRPL_PARTS", "2" if groups == 1 else "1")), groups=groups,
-              packed_order="chains" if small else "solves", dealt=dealt)
+              packed_order="chains" if (small or dealt is not None) else "solves", dealt=dealt)
     eng, ens0, T, proposer = S["eng"], S["ens0"], S["T"], S["proposer"]
     # history-free draws (pt.PTEnsemble "counter" mode): the chain walked does not depend on N, on prefetching
     # or on the chain groups
@@ -213,7 +229,7 @@ def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups
     ens = pt.PTEnsemble(ens0["chain_states"], T, S["evaluators"] if groups > 1 else S["evaluator"], rank=rank,
                         world=world, rng_mode="counter", streams=S["streams"], group=pt.LOCAL_ONLY if local_only else None,
                         device_decisions=decide == "device", gc_freeze=True,  # (the benchmark owns its process)
-                        regroup_by_cost=dealt)
+                        regroup_by_cost=dealt is not None)
     ens.initialise()
     temper_freq = 10
     ens.advance(proposer, a.warmup, temper_freq, prefetch)
@@ -259,6 +275,8 @@ def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups
                                "(n_T + n_params)] per replica exchange (every 10 iterations)",
                    "chains": n_chains, "solves_per_step": n_chains * 6, "parallelism": f"chain-blocks x{world}",
                    "prefetch": bool(prefetch), "chain_groups": groups,
+                   # a latency-bound ensemble: chains dealt to the groups by cost, this many groups one solve per SIMD
+                   "groups_dealt_by_cost": dealt is not None, "groups_one_solve_per_simd": dealt,
                    "decisions": "device" if ens.n_pipelined else "host",
                    "collectives_per_iteration": (ens.n_collectives - coll0) / max(1, a.steps),
                    "forward_solves_per_sec": n_chains * 6 * a.steps / dt, "accepted_moves": n_acc,

@@ -44,7 +44,7 @@ def main():
     irf_raw = np.load(os.path.join(REPO, "tests", "golden", "irf.npz"))["irf745_raw"]
     S = pt_bench.setup(a.chains, dev, 0, irf_raw=irf_raw, parts=a.parts, sort_by_cost=bool(a.sort), split_min=0,
                        sort_min=0, force_min_y=bool(a.force_min_y), groups=a.groups, packed_order=a.packed_order,
-                       dealt=bool(a.dealt))
+                       dealt=a.groups - 1 if a.dealt else None)
     ens = pt.PTEnsemble(S["ens0"]["chain_states"], S["T"], S["evaluators"] if a.groups > 1 else S["evaluator"], rank=0,
                         world=1, rng_mode=a.rng_mode, streams=S["streams"], device_decisions=bool(a.device_decisions),
                         regroup_by_cost=bool(a.dealt))

@@ -48,6 +48,9 @@ if [[ $SEC == *pt* ]]; then
 # ---- the parallel-tempering ensembles: contract lines, kernel statistics, counters of the likelihood kernel ----
 timeout -k 10 300 python bench.py --workload pt --chains 512 --steps 40 --warmup 10 > $O/${T}_bench_pt512_1gpu.json 2>> $O/${T}_bench.err
 timeout -k 10 300 python bench.py --workload pt --chains 64 --steps 40 --warmup 10 --no-cpu-baseline > $O/${T}_bench_pt64_1gpu.json 2>> $O/${T}_bench.err
+# ... and the blocks one GPU of four and of two would hold
+timeout -k 10 300 python bench.py --workload pt --chains 128 --steps 40 --warmup 10 --no-cpu-baseline > $O/${T}_bench_pt128_1gpu.json 2>> $O/${T}_bench.err
+timeout -k 10 300 python bench.py --workload pt --chains 256 --steps 40 --warmup 10 --no-cpu-baseline > $O/${T}_bench_pt256_1gpu.json 2>> $O/${T}_bench.err
 timeout -k 10 300 python bench.py --workload pt --chains 64 --steps 40 --warmup 10 --no-cpu-baseline --groups 1 --prefetch off --decide host > $O/${T}_bench_pt64_1gpu_plain.json 2>> $O/${T}_bench.err
 # ... and with the decisions on the host, as round 3 took them (two groups where prefetching, one otherwise)
 timeout -k 10 300 python bench.py --workload pt --chains 64 --steps 40 --warmup 10 --no-cpu-baseline --decide host > $O/${T}_bench_pt64_1gpu_host.json 2>> $O/${T}_bench.err

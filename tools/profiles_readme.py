@@ -80,12 +80,14 @@ b = load("bench_config5.json")
 if b:
     rows.append((f"`{T}_bench_config5.json`", f"`bench.py --workload config5`: **{b['value'] / 1e3:.1f} k solves/s** ({b['ms_per_step']:.2f} ms per 512-solve step, "
                                                f"{b['config']['streams']} streams), single stream {b['single_stream']['solves_per_sec'] / 1e3:.1f} k; kernel `{b['roofline']['kernel']}`"))
-for name in ("bench_pt512_1gpu.json", "bench_pt64_1gpu.json", "bench_pt512_1gpu_host.json", "bench_pt64_1gpu_host.json",
-             "bench_pt64_1gpu_plain.json"):
+for name in ("bench_pt512_1gpu.json", "bench_pt256_1gpu.json", "bench_pt128_1gpu.json", "bench_pt64_1gpu.json", "bench_pt512_1gpu_host.json",
+             "bench_pt64_1gpu_host.json", "bench_pt64_1gpu_plain.json"):
     b = load(name)
     if b:
-        rows.append((f"`{T}_{name}`", f"`bench.py --workload pt`: {b['config']['chains']} chains, {b['ms_per_step']:.2f} ms per iteration = {b['value'] / 1e3:.1f} k proposals/s "
-                                      f"(prefetch {b['config']['prefetch']}, {b['config']['chain_groups']} group(s), decisions on the {b['config'].get('decisions', 'host')})"))
+        c = b["config"]
+        dealt = f", chains dealt by cost, {c['groups_one_solve_per_simd']} group(s) one solve per SIMD" if c.get("groups_dealt_by_cost") else ""
+        rows.append((f"`{T}_{name}`", f"`bench.py --workload pt`: {c['chains']} chains, {b['ms_per_step']:.2f} ms per iteration = {b['value'] / 1e3:.1f} k proposals/s "
+                                      f"(prefetch {c['prefetch']}, {c['chain_groups']} group(s){dealt}, decisions on the {c.get('decisions', 'host')})"))
 for name, what in (("tail_decades.txt", "per-decade accuracy table (config 2 / config-3 geometry)"), ("heldout.txt", "the held-out converged set, per decade"),
                    ("heldout_large.txt", "the nx > 128 held-out converged set, per decade, through the SPIKE and the team backend"),
                    ("bind_trace.txt", "which half of the goal-oriented error test sets the step size, per decade of time (diagnostic build)"),

@@ -19,8 +19,8 @@ dev = torch.device("cuda", 0)
 groups = int(os.environ.get("PT_GROUPS", "3"))  # (not GROUPS: bash owns that name)
 small = groups > 1
 on_device = os.environ.get("PT_DECIDE", "device") == "device"
-dealt = groups > 2 and on_device  # as pt_bench._run sets the latency-bound ensemble up
-S = pt_bench.setup(n_chains, dev, 0, parts=1, groups=groups, dealt=dealt)
+dealt = groups > 2 and on_device  # as pt_bench._run sets the latency-bound 64-chain ensemble up
+S = pt_bench.setup(n_chains, dev, 0, parts=1, groups=groups, dealt=groups - 1 if dealt else None)
 ens = pt.PTEnsemble(S["ens0"]["chain_states"], S["T"], S["evaluators"] if groups > 1 else S["evaluator"], rng_mode="counter",
                     streams=S["streams"], group=pt.LOCAL_ONLY, device_decisions=on_device, regroup_by_cost=dealt)
 ens.initialise()
