@@ -310,6 +310,29 @@ def emit(line):
         os.write(_STDOUT_FD, data)
 
 
+def _leg_watchdog(rank, line, key):
+    """N > 1 only: a timer that ends the job if the leg it guards is still running after MTRPL_BENCH_LEG_TIMEOUT seconds
+    (default 420; the legs take about one minute) -- a collective that never returns would otherwise take the contract
+    line, already measured, with it.  Rank 0 emits the line with `{key: {"error": ...}}`; every rank exits 0 (the other
+    ranks a moment later, so that the launcher sees rank 0's output first)."""
+    import threading
+    limit = float(os.environ.get("MTRPL_BENCH_LEG_TIMEOUT", "420"))
+
+    def fire():
+        try:
+            if rank == 0 and line is not None:
+                line[key] = {"error": f"the {key} leg did not finish within {limit:.0f} s and was abandoned (bench.py watchdog)"}
+                emit(line)
+            else:
+                time.sleep(3.0)
+        finally:
+            os._exit(0)
+    t = threading.Timer(limit, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks as a CHILD
     `python -m torch.distributed.run` (never an exec, and before this process has made any GPU call -- counting devices
@@ -458,6 +481,7 @@ def main():
         k, v = kv.split("=")
         ctx.set_option(k, float(v))
         user_variant = user_variant or k in ("kernel_variant", "two_per_simd_min_batch")
+    # (--opt kernel_variant / two_per_simd_min_batch: the launches then take what the options say, per_simd stays 0)
     B = a.batch
     # rank r takes draws [r*B, (r+1)*B) of the seeded config-2 stream
     c = W.config2(B * world)
@@ -467,7 +491,7 @@ def main():
     descs, ini = batch.build_batch(c["states"][sl], W.indexes(), W.units(), c["iniPar"][sl], c["thickness"], c["nx"],
                                    nt, hmax=c["hmax"], meas=c["meas"], model=c["model"], ini_mode=c["ini_mode"])
     d_descs_drawn = torch.from_numpy(descs.view(np.uint8).reshape(-1)).to(dev)
-    cur = {"descs": d_descs_drawn}
+    cur = {"descs": d_descs_drawn, "per_simd": 0}
     d_ini = torch.from_numpy(ini).to(dev)
     d_t = torch.from_numpy(t_host).to(dev)
     S = max(1, a.streams)
@@ -479,9 +503,11 @@ def main():
 
     def step(k=0):
         o, st_, sa_ = outs[k % S]
-        ctx.check(L.lib().mtrpl_solve_batch_dev(ctx.handle, B, cur["descs"].data_ptr(), d_ini.data_ptr(), d_t.data_ptr(),
-                                                o.data_ptr(), st_.data_ptr(), sa_.data_ptr(),
-                                                int(c["nx"]), L.MODEL[c["model"]], streams[k % S].cuda_stream))
+        # (per_simd: 0 = the library picks the build of the wave kernel by the size of the launch; 2 = two solves per SIMD,
+        # said per launch by the caller who has several launches in flight -- mtrpl_solve_batch_dev2)
+        ctx.check(L.lib().mtrpl_solve_batch_dev2(ctx.handle, B, cur["descs"].data_ptr(), d_ini.data_ptr(), d_t.data_ptr(),
+                                                 o.data_ptr(), st_.data_ptr(), sa_.data_ptr(),
+                                                 int(c["nx"]), L.MODEL[c["model"]], streams[k % S].cuda_stream, cur["per_simd"]))
 
     for _ in range(a.warmup):
         step()
@@ -539,7 +565,7 @@ def main():
     if S > 1 and not user_variant:
         # several launches in flight: more solves than SIMDs, so the two-solves-per-SIMD form of the wave kernel
         # (a launch on its own would pick it from 1025 solves on)
-        ctx.set_option("two_per_simd_min_batch", 1)
+        cur["per_simd"] = 2
     if a.sort_by_cost:
         order = np.argsort(-stats_drawn[:, 7], kind="stable")
         cur["descs"] = torch.from_numpy(descs[order].view(np.uint8).reshape(-1)).to(dev)
@@ -574,7 +600,6 @@ def main():
     #          (from 1025 solves on a launch picks the two-solves-per-SIMD build by itself) ----
     one_launch = {}
     if not a.quick and not user_variant and not a.sort_by_cost:
-        ctx.set_option("two_per_simd_min_batch", 1025)
         for B2 in (2048, 4096):
             c2 = W.config2(B2 * world)
             sl2 = slice(rank * B2, (rank + 1) * B2)
@@ -605,7 +630,6 @@ def main():
                                    "kernel_ms": e0.elapsed_time(e1) / n2, "solves_per_sec": B2 * n2 / dt2,
                                    "all_solves_ok": bool((st2 == 0).all().item()) and bool(torch.isfinite(o2).all().item())}
             del d2, o2, st2, sa2
-        ctx.set_option("two_per_simd_min_batch", 1 if S > 1 else 1025)
 
     # measured HBM stream rate of this device (read + write of a 1 GiB buffer), next to the nominal peak
     copy_gbs = None
@@ -627,7 +651,6 @@ def main():
             copy_gbs = None
     acc = None
     if rank == 0:
-        ctx.set_option("two_per_simd_min_batch", 1025)
         try:
             acc = accuracy_object(ctx)
         except Exception as e:  # the contract line must not depend on the fixture
@@ -638,10 +661,7 @@ def main():
             api = _api_leg(local, dev)
         except Exception as e:  # the contract line must not depend on this leg
             api = {"error": repr(e)}
-    pt_leg = None
-    if not a.quick and not a.no_pt and not user_variant:
-        del outs, d_out, d_status, d_stats
-        pt_leg = _pt_leg(rank, world, local, dev, with_cpu=(cpu is not None), use_dist=use_dist)
+    line = None
     if rank == 0:
         A = algorithmic_bytes_per_solve(c["nx"], nt)
         achieved = A * B / (kern_ms * 1e-3) / 1e9
@@ -707,6 +727,24 @@ def main():
         line["accuracy"] = acc
         if api is not None:
             line["api"] = api
+        if world > 1:
+            line["multi_gpu"] = {
+                "first_run_on_hardware": True,
+                "note": "no multi-GPU node was available while this was built: before this run the N > 1 path had been "
+                        "exercised as one rank through RCCL and as two ranks sharing one GPU over gloo "
+                        "(tests/test_gpu_bench_line.py) and on CPU ranks (tests/test_pt_distributed.py); the timed region "
+                        "itself has no collective but the barrier and the max-over-ranks of the clock"}
+    # ---- BASELINE's second metric, after everything the contract line needs is in hand.  At N > 1 its legs are the only
+    # part of this program with collectives in them that no hardware has run before: a watchdog on every rank makes sure
+    # that a leg that hangs costs the line its `pt` object, not the line (rank 0 emits what it has, every rank leaves).
+    pt_leg = None
+    if not a.quick and not a.no_pt and not user_variant:
+        del outs, d_out, d_status, d_stats
+        wd = _leg_watchdog(rank, line, "pt") if world > 1 else None
+        pt_leg = _pt_leg(rank, world, local, dev, with_cpu=(cpu is not None), use_dist=use_dist)
+        if wd is not None:
+            wd.cancel()
+    if rank == 0:
         if pt_leg is not None:
             line["pt"] = pt_leg
         emit(line)

@@ -109,11 +109,13 @@ typedef struct mtrpl_solve_desc {
 typedef struct mtrpl_ctx mtrpl_ctx;
 
 /* ---- context ---------------------------------------------------------- */
-/* (Loading the library sets GPU_MAX_HW_QUEUES=16 in the process environment unless the caller has set it: the HIP
- * runtime reads it at its first call and multiplexes streams onto 4 hardware queues otherwise -- the streams the
- * pipelined mtrpl_solve_batch runs would then share queues with each other and with the caller's, and launches on one
- * queue serialise.  A process that has already used the GPU when it loads the library keeps whatever it started with:
- * the call is still correct, only slower -- host_streams = 0 then gives the one-launch rate back.) */
+/* (Hardware queues.  The HIP runtime multiplexes streams onto 4 hardware queues unless GPU_MAX_HW_QUEUES says otherwise
+ * when the runtime starts, i.e. at the first HIP call of the process; two streams on one queue serialise their launches.
+ * The streams the pipelined mtrpl_solve_batch runs, next to the caller's own, want 16 (measured: 390-430 k solves/s with
+ * 8 queues in a process that owns ten streams, 485-528 k with 16).  The LIBRARY NEVER TOUCHES THE ENVIRONMENT: a C caller
+ * exports GPU_MAX_HW_QUEUES=16 before its first HIP call; the Python package does so when it is imported unless
+ * MTRPL_KEEP_HW_QUEUES=1 is set (metrotrpl_amd.configure_runtime).  Without it every call is still correct, only
+ * slower -- host_streams = 0 then gives the one-launch rate back.) */
 int mtrpl_ctx_create(int device, mtrpl_ctx **ctx);
 int mtrpl_ctx_destroy(mtrpl_ctx *ctx);
 /* Frees the device memory the context holds but no longer uses (blocks its per-launch slab pool has outgrown: a slab
@@ -181,8 +183,9 @@ const char *mtrpl_version(void);
  *                                     gates), built twice: one solve per SIMD (6: the shortest solve) for launches
  *                                     of fewer than two_per_simd_min_batch solves, two per SIMD (3: 1.3-1.5x the
  *                                     solves per second when more solves than SIMDs are in flight) from there on
- *                                     (default 1025 = more solves than SIMDs on this device; set it to 1 when several
- *                                     smaller launches are in flight on different streams); a solve gives the same
+ *                                     (default 1025 = more solves than SIMDs on this device; a caller with several
+ *                                     smaller launches in flight on different streams says so per launch,
+ *                                     mtrpl_solve_batch_dev2, or sets the option to 1); a solve gives the same
  *                                     result on either build.  2: the wave kernel with fp64 blocks and an fp64
  *                                     re-solve (the exact linear algebra; agrees with the default inside the
  *                                     accuracy gate, not bitwise); 1 team kernel (the one traps and nx > 128 use).
@@ -225,6 +228,17 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
                           const double *d_ini, const double *d_tsteps, double *d_out,
                           int32_t *d_status, int32_t *d_stats, int32_t max_nx, int32_t model,
                           void *stream);
+/* The same launch with the build of the wave kernel chosen by the caller, for THIS launch only (std model, nx <= 128,
+ * kernel_variant 0; ignored elsewhere): solves_per_simd = 1 -- one solve per SIMD, the shortest solve --, 2 -- two per
+ * SIMD, 1.3-1.5x the solves per second once more solves than SIMDs are in flight --, 0 -- as mtrpl_solve_batch_dev
+ * chooses, by B against the option two_per_simd_min_batch.  For callers with several launches in flight on different
+ * streams (chain groups of a parallel-tempering ensemble, lanes of the dense sampler): what is on the device together
+ * is their knowledge, not a property of the context -- nothing has to flip a context option around a launch.
+ * A solve gives the same samples on either build. */
+int mtrpl_solve_batch_dev2(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_descs,
+                           const double *d_ini, const double *d_tsteps, double *d_out,
+                           int32_t *d_status, int32_t *d_stats, int32_t max_nx, int32_t model,
+                           void *stream, int32_t solves_per_simd);
 
 /* ---- a4/a5: RHS of the ODE system (forward_solver.py:332-418) ---------- */
 /* y, dy: [B, S] with S = 3nx+1 (std: N,P,E) or 4nx+1 (traps: N,Ntrap,P,E);

@@ -8,10 +8,22 @@ import os
 import subprocess
 import threading
 
-# Read by the HIP runtime at its first call (not at import): the pipelined host path and the engines' side streams need
-# more than the default 4 hardware queues (include/metrotrpl_amd.h, "context").  The library's own constructor does the
-# same for C callers; here it also covers `import torch` + a GPU call before the library is loaded.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+
+def configure_runtime(hw_queues=16):
+    """Ask the HIP runtime for `hw_queues` hardware queues (GPU_MAX_HW_QUEUES; the runtime reads it at its first call,
+    not at import).  The pipelined host path and the engines' side streams need more than the default 4: two streams on
+    one queue serialise their launches (include/metrotrpl_amd.h, "context").  A value the caller has exported wins.
+    Called when the package is imported, unless MTRPL_KEEP_HW_QUEUES=1 says to leave the process environment alone --
+    it is a process-wide setting that every other HIP user of the process (PyTorch, RCCL) and every child process sees
+    (the C library itself never touches the environment).  Returns the value in force, or None when
+    nothing was set."""
+    if os.environ.get("MTRPL_KEEP_HW_QUEUES") == "1":
+        return os.environ.get("GPU_MAX_HW_QUEUES")
+    return os.environ.setdefault("GPU_MAX_HW_QUEUES", str(int(hw_queues)))
+
+
+configure_runtime()
 
 import numpy as np
 
@@ -73,6 +85,7 @@ SIGNATURES = {
     "mtrpl_solve_batch": (C.c_int, [_vp, C.c_int64, _vp, _dp, C.c_int64, _dp, C.c_int64, _dp, C.c_int64,
                                     _ip, _ip]),
     "mtrpl_solve_batch_dev": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp]),
+    "mtrpl_solve_batch_dev2": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, _vp, C.c_int32]),
     "mtrpl_rhs_batch": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp]),
     "mtrpl_E_field": (C.c_int, [_vp, C.c_int64, C.c_int32, _dp, _dp, C.c_double, C.c_double, C.c_double,
                                 C.c_double, C.c_double, _dp]),
@@ -148,10 +161,16 @@ def lib():
 
 
 class Context:
-    """mtrpl_ctx: one per process and GPU; blocking calls; not thread-safe."""
+    """mtrpl_ctx: one per process and GPU; blocking calls; not thread-safe.
+
+    Pinned host memory handed out by `PinnedBuffer` belongs to the context (mtrpl_ctx_destroy frees it): while any such
+    buffer is alive `close()` only marks the context closed -- every later call through it raises -- and the native
+    context goes with the last buffer, so that an array a caller still holds never points at freed memory."""
 
     def __init__(self, device=0):
         self._h = _vp()
+        self._pinned_live = 0      # PinnedBuffers alive
+        self._closed = False
         rc = lib().mtrpl_ctx_create(int(device), C.byref(self._h))
         if rc != OK:
             self._h = None
@@ -159,19 +178,29 @@ class Context:
                                "no MI355X (gfx950) device visible. There is no CPU fallback.")
         self.device = int(device)
 
-    def close(self):
+    def _destroy(self):
         if getattr(self, "_h", None):
             lib().mtrpl_ctx_destroy(self._h)
             self._h = None
 
+    def close(self):
+        self._closed = True
+        self.__dict__.pop("_pinned_free", None)  # (pooled buffers nobody holds: they go with the context)
+        if getattr(self, "_pinned_live", 0) == 0:
+            self._destroy()
+
     def __del__(self):
         try:
-            self.close()
+            # (a live PinnedBuffer holds a reference to its context: when this runs there is none)
+            self._closed = True
+            self._destroy()
         except Exception:
             pass
 
     @property
     def handle(self):
+        if getattr(self, "_closed", False):
+            raise RuntimeError("metrotrpl_amd: this context has been closed")
         return self._h
 
     def check(self, rc):
@@ -186,28 +215,32 @@ class Context:
         raise RuntimeError(f"metrotrpl_amd error {rc}: {msg}")
 
     def set_option(self, key, value):
-        self.check(lib().mtrpl_set_option(self._h, key.encode(), float(value)))
+        self.check(lib().mtrpl_set_option(self.handle, key.encode(), float(value)))
 
     def get_option(self, key):
         v = C.c_double()
-        self.check(lib().mtrpl_get_option(self._h, key.encode(), C.byref(v)))
+        self.check(lib().mtrpl_get_option(self.handle, key.encode(), C.byref(v)))
         return v.value
 
     def trim(self):
         """Free device memory the context no longer uses (mtrpl_ctx_trim: synchronises the device -- quiet points only)."""
-        self.check(lib().mtrpl_ctx_trim(self._h))
+        self.check(lib().mtrpl_ctx_trim(self.handle))
 
 
 class PinnedBuffer:
     """`nbytes` of pinned host memory from the library (mtrpl_host_alloc) as the base object of numpy arrays
     (`np.asarray(buf)` is a float64 view that keeps `buf` alive).  mtrpl_solve_batch copies straight into such memory
     while later sub-launches compute.  Pinning is slow (page by page), so freed buffers go back to a small per-context
-    free-list by size instead of to the runtime."""
-    _KEEP_BYTES = 1 << 30
+    free-list by size instead of to the runtime (at most `_KEEP_BYTES` in total; what does not fit is freed).
+
+    The memory is the CONTEXT's: a live buffer keeps the native context alive past `Context.close()` (see there).
+    Every byte a caller keeps this way stays page-locked -- results that are kept for long belong in ordinary arrays
+    (`batch.solve_batch` returns those unless asked for `pinned=True`)."""
+    _KEEP_BYTES = 256 << 20
 
     def __init__(self, ctx, nbytes):
         nbytes = max(8, int(nbytes) + (-int(nbytes)) % 8)
-        self.ctx, self.nbytes = ctx, nbytes
+        self.ctx, self.nbytes, self.ptr = ctx, nbytes, None
         pool = ctx.__dict__.setdefault("_pinned_free", {})
         have = pool.get(nbytes)
         if have:
@@ -216,18 +249,24 @@ class PinnedBuffer:
             p = _vp()
             ctx.check(lib().mtrpl_host_alloc(ctx.handle, nbytes, C.byref(p)))
             self.ptr = p.value
+        ctx._pinned_live += 1
         self.__array_interface__ = {"data": (self.ptr, False), "shape": (nbytes // 8,), "typestr": "<f8", "version": 3}
 
     def __del__(self):
         try:
             ctx = self.ctx
-            if not getattr(ctx, "_h", None):
-                return  # the context went first and took its pinned memory with it
+            if self.ptr is None or not getattr(ctx, "_h", None):
+                return
+            ctx._pinned_live -= 1
+            if ctx._closed:
+                if ctx._pinned_live == 0:
+                    ctx._destroy()  # the last buffer of a closed context takes the native context with it
+                return
             pool = ctx.__dict__.setdefault("_pinned_free", {})
             if sum(k * len(v) for k, v in pool.items()) + self.nbytes <= self._KEEP_BYTES:
                 pool.setdefault(self.nbytes, []).append(self.ptr)
             else:
-                lib().mtrpl_host_free(ctx.handle, self.ptr)
+                lib().mtrpl_host_free(ctx._h, self.ptr)
         except Exception:
             pass
 

@@ -50,15 +50,15 @@ template <class T> __device__ inline T uniform(T v)
 }
 __device__ inline int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // ... and when the compiler can see for itself that v is uniform it drops the readfirstlane and leaves v in the vector register
-// its arithmetic produced it in (floating point is on the vector unit only): the move as an instruction it cannot see through.
-// The wait states are part of it: a scalar register written by a vector instruction may be read by the next vector
-// instruction but one at the earliest (two wait states on this ISA), and the value read may come from the transcendental
-// unit (one); the compiler inserts such s_nops around its own instructions, not around the inside of an asm statement --
-// without them the spill of this register, two instructions on, stored whatever the register held before.
+// its arithmetic produced it in (floating point is on the vector unit only).  The EMPTY asm with a scalar-register
+// constraint is what keeps the value in a scalar register: whatever the compiler makes of the builtin, the operand of
+// the asm has to be in an SGPR, and the only way there from a VGPR is a v_readfirstlane the COMPILER emits -- so the
+// hazard recogniser sees the producing instruction and owns its wait states (round 5 had the v_readfirstlane inside
+// the asm with hand-counted s_nops, valid only for the consumers of that day: ADVICE r5).
 __device__ inline float to_scalar(float v)
 {
-    int r;
-    asm("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(r) : "v"(v));
+    int r = __builtin_amdgcn_readfirstlane(__float_as_int(v));
+    asm volatile("" : "+s"(r));
     return __int_as_float(r);
 }
 

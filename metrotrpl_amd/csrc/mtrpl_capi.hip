@@ -74,11 +74,15 @@ struct mtrpl_ctx {
     std::vector<void *> host_allocs;  // mtrpl_host_alloc
 };
 
+// A failed HIP call ends the entry point -- after whatever the blocking host-pointer entry points have already enqueued
+// on the context's own stream has drained: their copies go into the CALLER's host buffers and out of device scratch the
+// next call reuses, and neither may be touched by work still in flight once the error code is back.
 #define HIP_TRY(ctx, expr)                                                                   \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
         if (e_ != hipSuccess) {                                                              \
             (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
+            if ((ctx)->stream) (void)hipStreamSynchronize((ctx)->stream);                    \
             return MTRPL_ERR_DEVICE;                                                         \
         }                                                                                    \
     } while (0)
@@ -440,13 +444,14 @@ extern "C" {
 
 const char *mtrpl_version(void) { return "metrotrpl_amd 0.3 (gfx950)"; }
 
-// HIP multiplexes streams onto 4 hardware queues by default; the pipelined host path runs streams of its own next to
-// whatever the caller has (PyTorch's streams, other contexts), and two streams on one queue serialise their launches
-// (measured, B = 8192 host to host: 520 k solves/s, 390-430 k when two of the sub-launch streams share a queue -- which
-// happened with 8 queues as soon as the process owned ten streams, and not with 16: profiles/r05_api_queues.txt).  The
-// runtime reads GPU_MAX_HW_QUEUES when it starts, i.e. at the first HIP call of the process: set here, when the library
-// is LOADED, unless the caller has set it.  A process that has used the GPU before loading this library keeps its own.
-__attribute__((constructor)) static void mtrpl_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// HIP multiplexes streams onto 4 hardware queues by default (GPU_MAX_HW_QUEUES, read when the runtime starts, i.e. at the
+// first HIP call of the process); the pipelined host path runs streams of its own next to whatever the caller has, and two
+// streams on one queue serialise their launches (measured, B = 8192 host to host: 520 k solves/s, 390-430 k when two of the
+// sub-launch streams share a queue -- with 8 queues as soon as the process owned ten streams, not with 16:
+// profiles/r05_api_queues.txt).  The library does NOT touch the environment (rounds 4-5 did, from a load-time
+// constructor: a process-wide setting changed behind the back of every other HIP user of the process, by a setenv that
+// is not safe against a concurrent getenv of a multi-threaded host -- ADVICE r5): a C caller exports
+// GPU_MAX_HW_QUEUES=16 itself, the Python package does it at import unless told not to (metrotrpl_amd/_lib.py).
 
 int mtrpl_ctx_create(int device, mtrpl_ctx **out)
 {
@@ -586,7 +591,7 @@ int mtrpl_get_option(const mtrpl_ctx *ctx, const char *key, double *value)
 
 static int launch_solves(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
                          const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats, int32_t max_nx,
-                         int32_t model, void *stream, int64_t in_flight);
+                         int32_t model, void *stream, int64_t in_flight, int32_t per_simd = 0);
 
 int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
                           const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats, int32_t max_nx,
@@ -595,12 +600,22 @@ int mtrpl_solve_batch_dev(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_d
     return launch_solves(ctx, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, max_nx, model, stream, B);
 }
 
+// ... with the choice between the two builds of the wave kernel made by the CALLER, per launch (0: as above)
+int mtrpl_solve_batch_dev2(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
+                           const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats, int32_t max_nx,
+                           int32_t model, void *stream, int32_t solves_per_simd)
+{
+    if (solves_per_simd < 0 || solves_per_simd > 2)
+        return bad(ctx, MTRPL_ERR_BAD_ARG, "solves_per_simd must be 0 (by the size of the launch), 1 or 2");
+    return launch_solves(ctx, B, d_descs, d_ini, d_tsteps, d_out, d_status, d_stats, max_nx, model, stream, B, solves_per_simd);
+}
+
 // in_flight: the solves the caller has (or is about to have) on the device together with this launch -- what the choice
 // between the one- and the two-solves-per-SIMD build of the wave kernel goes by (a sub-launch of the pipelined host path
-// says the size of the whole call)
+// says the size of the whole call); per_simd 1 / 2: the caller has chosen (mtrpl_solve_batch_dev2)
 static int launch_solves(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_descs, const double *d_ini,
                          const double *d_tsteps, double *d_out, int32_t *d_status, int32_t *d_stats, int32_t max_nx,
-                         int32_t model, void *stream, int64_t in_flight)
+                         int32_t model, void *stream, int64_t in_flight, int32_t per_simd)
 {
     if (!ctx) return MTRPL_ERR_BAD_ARG;
     if (B <= 0) return MTRPL_OK;
@@ -627,7 +642,7 @@ static int launch_solves(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *d_de
     //   wave  (2): fp64 blocks and an fp64 re-solve: the exact linear algebra, one solve per SIMD
     int variant = ctx->kernel_variant;
     if (variant == 0)
-        variant = (std::max(B, in_flight) >= ctx->two_per_simd_min_batch) ? 3 : 6;
+        variant = per_simd ? (per_simd == 2 ? 3 : 6) : ((std::max(B, in_flight) >= ctx->two_per_simd_min_batch) ? 3 : 6);
     const bool ct = default_tune(ctx->tune);
 #define MTRPL_WAVE(KERNEL)                                                                                            \
     do {                                                                                                              \
@@ -754,7 +769,10 @@ int mtrpl_solve_batch(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *descs, 
         HIP_TRY(ctx, hipMemsetAsync(dout.p, 0, sizeof(double) * (size_t)n_out, s));
         rc = mtrpl_solve_batch_dev(ctx, B, dd.as<mtrpl_solve_desc>(), di.as<double>(), dt.as<double>(), dout.as<double>(),
                                    dst.as<int32_t>(), dstat.as<int32_t>(), max_nx, descs[0].model, s);
-        if (rc != MTRPL_OK) return rc;
+        if (rc != MTRPL_OK) {
+            (void)hipStreamSynchronize(s);
+            return rc;
+        }
         HIP_TRY(ctx, hipMemcpyAsync(out, dout.p, sizeof(double) * (size_t)n_out, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipMemcpyAsync(status, dst.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
         if (stats) HIP_TRY(ctx, hipMemcpyAsync(stats, dstat.p, sizeof(int32_t) * 8 * B, hipMemcpyDeviceToHost, s));
@@ -762,63 +780,67 @@ int mtrpl_solve_batch(mtrpl_ctx *ctx, int64_t B, const mtrpl_solve_desc *descs, 
         return MTRPL_OK;
     }
 
-    const bool direct = host_pinned(out);
+    // (pinned from its first to its last byte: a view that starts in a pinned allocation may end outside it)
+    const bool direct = host_pinned(out) && host_pinned(out + (n_out - 1));
     const int nslots = direct ? 0 : (int)std::min<int64_t>(nchunks, 2 * ns);
     size_t slot_bytes = 0;
     for (int64_t j = 0; j < nchunks; ++j)
         slot_bytes = std::max(slot_bytes, sizeof(double) * (size_t)(upto[j] - (j ? upto[j - 1] : 0)));
     rc = pipe_setup(ctx, ns, nslots, slot_bytes);
     if (rc != MTRPL_OK) return rc;
+    // From the first enqueue on NO failure returns early: the device scratch, the staging ring and the streams are the
+    // context's, the next call reuses (or reallocates) them, so whatever this call has put in flight is waited for at
+    // the common exit below before any status goes back.
+    int fail = MTRPL_OK;
+    auto ok = [&](hipError_t e, const char *what) {
+        if (e == hipSuccess) return true;
+        if (fail == MTRPL_OK) {
+            ctx->err = std::string("pipelined solve, ") + what + ": " + hipGetErrorString(e);
+            fail = MTRPL_ERR_DEVICE;
+        }
+        return false;
+    };
     // inputs on the first stream; the others start behind them
     hipStream_t s0 = ctx->pipe[0];
-    HIP_TRY(ctx, hipMemcpyAsync(dd.p, descs, sizeof(mtrpl_solve_desc) * B, hipMemcpyHostToDevice, s0));
-    if (n_ini > 0 && ini) HIP_TRY(ctx, hipMemcpyAsync(di.p, ini, sizeof(double) * (size_t)n_ini, hipMemcpyHostToDevice, s0));
-    HIP_TRY(ctx, hipMemcpyAsync(dt.p, tsteps, sizeof(double) * (size_t)n_t, hipMemcpyHostToDevice, s0));
-    HIP_TRY(ctx, hipMemsetAsync(dout.p, 0, sizeof(double) * (size_t)n_out, s0));  // (gaps between traces read as zero, as ever)
-    HIP_TRY(ctx, hipEventRecord(ctx->pipe_in, s0));
-    for (int q = 1; q < ns; ++q) HIP_TRY(ctx, hipStreamWaitEvent(ctx->pipe[q], ctx->pipe_in, 0));
+    ok(hipMemcpyAsync(dd.p, descs, sizeof(mtrpl_solve_desc) * B, hipMemcpyHostToDevice, s0), "descriptor upload") &&
+        (!(n_ini > 0 && ini) || ok(hipMemcpyAsync(di.p, ini, sizeof(double) * (size_t)n_ini, hipMemcpyHostToDevice, s0), "initial-condition upload")) &&
+        ok(hipMemcpyAsync(dt.p, tsteps, sizeof(double) * (size_t)n_t, hipMemcpyHostToDevice, s0), "time-grid upload") &&
+        ok(hipMemsetAsync(dout.p, 0, sizeof(double) * (size_t)n_out, s0), "output clear") &&  // (gaps between traces read as zero, as ever)
+        ok(hipEventRecord(ctx->pipe_in, s0), "hipEventRecord");
+    for (int q = 1; q < ns && fail == MTRPL_OK; ++q) ok(hipStreamWaitEvent(ctx->pipe[q], ctx->pipe_in, 0), "hipStreamWaitEvent");
 
-    int fail = MTRPL_OK;
-    auto drain = [&](int64_t j) -> int {  // sub-launch j's samples from its staging slot into the caller's buffer
+    auto drain = [&](int64_t j) {  // sub-launch j's samples from its staging slot into the caller's buffer
         const int slot = (int)(j % nslots);
-        HIP_TRY(ctx, hipEventSynchronize(ctx->pipe_done[slot]));
+        if (!ok(hipEventSynchronize(ctx->pipe_done[slot]), "hipEventSynchronize")) return;
         const int64_t a = j ? upto[j - 1] : 0;
         std::memcpy(out + a, static_cast<char *>(ctx->stage) + (size_t)slot * slot_bytes, sizeof(double) * (size_t)(upto[j] - a));
-        return MTRPL_OK;
     };
     int64_t drained = 0;
     for (int64_t j = 0; j < nchunks && fail == MTRPL_OK; ++j) {
         if (!direct && j >= nslots) {  // the slot this sub-launch copies into is free once its previous user is out
-            fail = drain(j - nslots);
+            drain(j - nslots);
             drained = j - nslots + 1;
             if (fail != MTRPL_OK) break;
         }
         hipStream_t s = ctx->pipe[j % ns];
         const int64_t k0 = j * chunk, nb = std::min(B, k0 + chunk) - k0;
-        fail = launch_solves(ctx, nb, dd.as<mtrpl_solve_desc>() + k0, di.as<double>(), dt.as<double>(), dout.as<double>(),
-                             dst.as<int32_t>() + k0, dstat.as<int32_t>() + 8 * k0, max_nx, descs[0].model, s, B);
-        if (fail != MTRPL_OK) break;
+        const int rl = launch_solves(ctx, nb, dd.as<mtrpl_solve_desc>() + k0, di.as<double>(), dt.as<double>(), dout.as<double>(),
+                                     dst.as<int32_t>() + k0, dstat.as<int32_t>() + 8 * k0, max_nx, descs[0].model, s, B);
+        if (rl != MTRPL_OK) {  // (its message is in ctx->err)
+            if (fail == MTRPL_OK) fail = rl;
+            break;
+        }
         const int64_t a = j ? upto[j - 1] : 0;
         void *dst_host = direct ? static_cast<void *>(out + a)
                                 : static_cast<void *>(static_cast<char *>(ctx->stage) + (size_t)(j % nslots) * slot_bytes);
-        hipError_t e = hipMemcpyAsync(dst_host, dout.as<double>() + a, sizeof(double) * (size_t)(upto[j] - a),
-                                      hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess && !direct) e = hipEventRecord(ctx->pipe_done[j % nslots], s);
-        if (e != hipSuccess) {
-            ctx->err = std::string("pipelined solve, device-to-host copy: ") + hipGetErrorString(e);
-            fail = MTRPL_ERR_DEVICE;
-        }
+        if (ok(hipMemcpyAsync(dst_host, dout.as<double>() + a, sizeof(double) * (size_t)(upto[j] - a), hipMemcpyDeviceToHost, s),
+               "device-to-host copy") && !direct)
+            ok(hipEventRecord(ctx->pipe_done[j % nslots], s), "hipEventRecord");
     }
     if (!direct)
-        for (int64_t j = drained; j < nchunks && fail == MTRPL_OK; ++j) fail = drain(j);
+        for (int64_t j = drained; j < nchunks && fail == MTRPL_OK; ++j) drain(j);
     // nothing of this call may be in flight when it returns, whatever happened above (the buffers are the context's)
-    for (int q = 0; q < ns; ++q) {
-        const hipError_t e = hipStreamSynchronize(ctx->pipe[q]);
-        if (e != hipSuccess && fail == MTRPL_OK) {
-            ctx->err = std::string("pipelined solve, hipStreamSynchronize: ") + hipGetErrorString(e);
-            fail = MTRPL_ERR_DEVICE;
-        }
-    }
+    for (int q = 0; q < ns; ++q) ok(hipStreamSynchronize(ctx->pipe[q]), "hipStreamSynchronize");
     if (fail != MTRPL_OK) return fail;
     HIP_TRY(ctx, hipMemcpy(status, dst.p, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
     if (stats) HIP_TRY(ctx, hipMemcpy(stats, dstat.p, sizeof(int32_t) * 8 * B, hipMemcpyDeviceToHost));

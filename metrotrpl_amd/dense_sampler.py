@@ -49,20 +49,19 @@ def simulate(engine, X, temperature=1.0, chunk=1024, lanes=3):
         pool.append(engine.clone())
     streams = L.shared_streams(engine.dev, lanes)
     # every chunk shares the device with the other lanes' chunks: more solves than SIMDs in flight whatever a chunk's
-    # size, so each launch takes the two-solves-per-SIMD build of the wave kernel (same results)
-    keep = engine.ctx.get_option("two_per_simd_min_batch")
-    engine.ctx.set_option("two_per_simd_min_batch", 1)
-    try:
-        pending = [None] * lanes
-        for k, a in enumerate(starts):
-            q = k % lanes
-            if pending[q] is not None:
-                a0, h = pending[q]
-                P[a0:a0 + chunk] = h.result()[:, :, 0].sum(axis=1)
-            pending[q] = (a, pool[q].eval_async(X[a:a + chunk], [temperature], streams[q]))
-        order = sorted((p for p in pending if p is not None), key=lambda p: p[0])
-        for a0, h in order:
+    # size, so each lane's launches take the two-solves-per-SIMD build of the wave kernel (same results) -- said per
+    # launch (LikelihoodEngine.per_simd -> mtrpl_solve_batch_dev2): the lanes are this sampler's own clones, nothing of
+    # the context other engines share is touched
+    for lane in pool[:lanes]:
+        lane.per_simd = 2
+    pending = [None] * lanes
+    for k, a in enumerate(starts):
+        q = k % lanes
+        if pending[q] is not None:
+            a0, h = pending[q]
             P[a0:a0 + chunk] = h.result()[:, :, 0].sum(axis=1)
-    finally:
-        engine.ctx.set_option("two_per_simd_min_batch", keep)
+        pending[q] = (a, pool[q].eval_async(X[a:a + chunk], [temperature], streams[q]))
+    order = sorted((p for p in pending if p is not None), key=lambda p: p[0])
+    for a0, h in order:
+        P[a0:a0 + chunk] = h.result()[:, :, 0].sum(axis=1)
     return P

@@ -82,6 +82,9 @@ class LikelihoodEngine:
         self._ticks = None
         self.timing = None  # a list: launch() appends (stream, e0, e1, e2, n_solves) HIP-event triples around
         #                     the solve and the likelihood kernel of every block (bench.py: roofline)
+        self.per_simd = 0   # 1 / 2: this engine's launches run the one- / two-solves-per-SIMD build of the wave kernel
+        #                     (mtrpl_solve_batch_dev2: a caller with several engines in flight knows what shares the
+        #                     device); 0: by the size of the launch
 
     def _ensure(self, n_solves, nT):
         torch = self.torch
@@ -374,10 +377,10 @@ class LikelihoodEngine:
             if self.timing is not None:
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                 ev[0].record(st)
-            self.ctx.check(lib.mtrpl_solve_batch_dev(h, b - a, self.d_descs.data_ptr() + a * sd, self.d_ini.data_ptr(),
-                                                     self.d_t.data_ptr(), self.d_sig.data_ptr(),
-                                                     self.d_status.data_ptr() + 4 * a, self.d_stats.data_ptr() + 32 * a,
-                                                     self.nx, L.MODEL[self.model], s))
+            self.ctx.check(lib.mtrpl_solve_batch_dev2(h, b - a, self.d_descs.data_ptr() + a * sd, self.d_ini.data_ptr(),
+                                                      self.d_t.data_ptr(), self.d_sig.data_ptr(),
+                                                      self.d_status.data_ptr() + 4 * a, self.d_stats.data_ptr() + 32 * a,
+                                                      self.nx, L.MODEL[self.model], s, int(self.per_simd)))
             if self.timing is not None:
                 ev[1].record(st)
             self.ctx.check(lib.mtrpl_loglik_batch_dev(h, b - a, self.d_like.data_ptr() + a * sl, self.d_sig.data_ptr(),

@@ -51,11 +51,12 @@ def synthetic_data(irf_tables, nx, times):
 
 
 def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=True, split_min=2048, sort_min=1024,
-          ctx=None, force_min_y=False, groups=1, packed_order="chains", dealt=None):
+          ctx=None, force_min_y=False, groups=1, packed_order="chains", dealt=None, two_per_simd=False):
     """The config-3/4 problem on one rank: engine(s), ladder, evaluator(s) and proposer.  groups > 1: one
     engine, evaluator and HIP stream per chain group of pt.PTEnsemble.  `dealt` = k: evaluators for an ensemble that deals its
     chains to the groups by cost (`PTEnsemble(regroup_by_cost=True)`: the two go together) -- they report what a chain cost,
-    the first k groups (the expensive chains) run one solve per SIMD and the others two."""
+    the first k groups (the expensive chains) run one solve per SIMD and the others two.  `two_per_simd`: every group's
+    launches, whatever their size, run two solves per SIMD (several throughput-bound groups share the device)."""
     import torch
     times = W.default_times()
     ctx = ctx or L.default_context(local)
@@ -88,18 +89,16 @@ def setup(n_chains, dev, local=0, nx=128, irf_raw=None, parts=2, sort_by_cost=Tr
         # the first `dealt` groups (the expensive chains) run one solve per SIMD and the others two: nobody waits for a SIMD,
         # and the solves that take 1.4x as long are the ones with time to spare.  64 chains, two iterations per launch:
         # 396 + 378 + 189 of 1024 SIMDs (all one per SIMD: 1152); 256 chains, one iteration: 516 + 255 + 255.
-        per_simd = None if dealt is None else (1 if g_ < dealt else 2)
+        # (said per launch -- LikelihoodEngine.per_simd -> mtrpl_solve_batch_dev2 --, not by flipping an option of the context
+        # the groups share around every launch: ADVICE r5)
+        if dealt is not None:
+            eng.per_simd = 1 if g_ < dealt else 2
+        elif two_per_simd:
+            eng.per_simd = 2
 
         def launch_packed(d_descs, n_solves, temps):
             eng.use_packed(d_descs, n_solves)
-            if per_simd:  # (the library picks the kernel build when the launch is issued: a host-side switch around the call)
-                keep = ctx.get_option("two_per_simd_min_batch")
-                ctx.set_option("two_per_simd_min_batch", 1 if per_simd == 2 else 1 << 30)
-            try:
-                return eng.launch(d_T, len(temps)).view(-1, eng.M, len(temps)).sum(dim=1)
-            finally:
-                if per_simd:
-                    ctx.set_option("two_per_simd_min_batch", keep)
+            return eng.launch(d_T, len(temps)).view(-1, eng.M, len(temps)).sum(dim=1)
         evaluator.pack_rows, evaluator.launch_packed, evaluator.packable = eng.pack_rows, launch_packed, eng.packable()
 
         # pt._DecidePipe: the two decisions of a launch and the pick of the next launch's descriptors, one kernel each
@@ -187,6 +186,7 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
                       and os.environ.get("MTRPL_PT_NO_REGROUP") != "1") else None
     ctx = L.default_context(local)
     restore = {}
+    two_per_simd = False  # every group's launches on the two-solves-per-SIMD build (said per launch, by the engines)
 
     def set_option(key, value):
         restore.setdefault(key, ctx.get_option(key))
@@ -197,19 +197,19 @@ def run(a, rank, world, local, dev, cpu_baseline_fn=None):
         # wave do, blocks of twelve wait until that queue has drained (include/metrotrpl_amd.h, loglik_wave_blocks).
         # Latency-bound (dealt): each group's evaluator says which build its launches use, and there is room for the
         # twelve-wave blocks (256 chains: 4.24 ms per iteration against 4.50 with blocks of one wave, 4.84 not dealt)
-        set_option("two_per_simd_min_batch", 1)
+        two_per_simd = dealt is None
         set_option("loglik_wave_blocks", float(os.environ.get("MTRPL_LL_WAVE", "0" if dealt is not None else "1")))
     for kv in getattr(a, "opt", []) or []:
         k_, v_ = kv.split("=")
         set_option(k_, float(v_))
     try:
-        return _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups, decide, dealt)
+        return _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups, decide, dealt, two_per_simd)
     finally:
         for k_, v_ in restore.items():  # the context is the process's default one: other bench legs use it too
             ctx.set_option(k_, v_)
 
 
-def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups, decide, dealt):
+def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups, decide, dealt, two_per_simd=False):
     import torch
     import torch.distributed as dist
     # the order the solves of a launch are issued in: the small launches of the prefetching ensemble (launches of a few
@@ -219,7 +219,7 @@ def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups
     small = prefetch and groups > 1
     S = setup(n_chains, dev, local, sort_by_cost=os.environ.get("MTRPL_NO_SORT") != "1",
               parts=int(os.environ.get("MTRPL_PARTS", "2" if groups == 1 else "1")), groups=groups,
-              packed_order="chains" if (small or dealt is not None) else "solves", dealt=dealt)
+              packed_order="chains" if (small or dealt is not None) else "solves", dealt=dealt, two_per_simd=two_per_simd)
     eng, ens0, T, proposer = S["eng"], S["ens0"], S["T"], S["proposer"]
     # history-free draws (pt.PTEnsemble "counter" mode): the chain walked does not depend on N, on prefetching
     # or on the chain groups
@@ -303,8 +303,9 @@ def _run(a, rank, world, local, dev, cpu_baseline_fn, n_chains, prefetch, groups
         n_solve = [n for *_, n in timing]
         kern_ms = float(np.mean(t_solve))
         # launches of more than 1024 solves go to the two-solves-per-SIMD form of the wave kernel (include/metrotrpl_amd.h)
-        kern_name = ("solve_kernel_wave2" if float(np.mean(n_solve)) >= L.default_context(local).get_option("two_per_simd_min_batch")
-                     else "solve_kernel_wave1")
+        two = eng.per_simd == 2 or (eng.per_simd == 0 and
+                                    float(np.mean(n_solve)) >= L.default_context(local).get_option("two_per_simd_min_batch"))
+        kern_name = "solve_kernel_wave2" if two else "solve_kernel_wave1"
         achieved = A * float(np.mean(n_solve)) / (kern_ms * 1e-3) / 1e9
         line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBS, "kernel": kern_name, "kernel_ms": kern_ms,

@@ -82,3 +82,29 @@ def test_only_tests_smoke_and_cpu_baseline_touch_the_oracle():
         while not src[j].startswith("def "):
             j -= 1
         assert src[j].startswith(("def cpu_baseline", "def cpu_baseline_pt", "def _cpu_one")), src[j]
+
+
+def test_hardware_queue_setting_is_the_packages_and_can_be_declined(lib):
+    """GPU_MAX_HW_QUEUES (include/metrotrpl_amd.h, "context"): the C library never touches the environment (rounds 4-5 did,
+    from a load-time constructor: ADVICE r5); importing the Python package sets 16 unless the caller has exported a value
+    or MTRPL_KEEP_HW_QUEUES=1 declines."""
+    import subprocess
+    import sys
+    from metrotrpl_amd import _lib
+    code = ("import os, ctypes\n"
+            "ctypes.CDLL(%r)\n"
+            "print('after dlopen:', os.environ.get('GPU_MAX_HW_QUEUES'))\n"
+            "import metrotrpl_amd\n"
+            "print('after import:', os.environ.get('GPU_MAX_HW_QUEUES'))\n" % _lib.LIB_PATH)
+
+    def run(extra):
+        env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "MTRPL_KEEP_HW_QUEUES")}
+        env.update(extra)
+        env["PYTHONPATH"] = REPO + os.pathsep + env.get("PYTHONPATH", "")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-800:]
+        return r.stdout
+
+    assert run({}) == "after dlopen: None\nafter import: 16\n"
+    assert run({"MTRPL_KEEP_HW_QUEUES": "1"}) == "after dlopen: None\nafter import: None\n"
+    assert run({"GPU_MAX_HW_QUEUES": "8"}) == "after dlopen: 8\nafter import: 8\n"

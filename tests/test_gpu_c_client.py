@@ -31,7 +31,9 @@ def test_c_client_gets_the_same_traces(tmp_path):
         np.array([len(descs), len(t)], dtype=np.int64).tofile(f)
         descs.tofile(f)
         t.tofile(f)
-    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=120)
+    # (a C caller exports the hardware-queue setting itself: the library never touches the environment)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-500:])
     assert "24 solves" in r.stdout and "bad-argument call -> 1" in r.stdout, r.stdout
     raw = np.fromfile(fout, dtype=np.uint8)
@@ -41,6 +43,6 @@ def test_c_client_gets_the_same_traces(tmp_path):
     np.testing.assert_array_equal(sig_c, sig)
     # ... and through the pipelined host path: a pinned output buffer from mtrpl_host_alloc, three sub-launches of 8 solves
     fout2 = str(tmp_path / "out2.bin")
-    r = subprocess.run([exe, fin, fout2, "8"], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([exe, fin, fout2, "8"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-500:])
     np.testing.assert_array_equal(np.fromfile(fout2, dtype=np.uint8), raw)

@@ -155,17 +155,80 @@ def test_pipelined_host_solve_batch_equals_the_blocking_launch():
     st, _ = _host_call(ctx, rev, ini, t, out)
     np.testing.assert_array_equal(out, ref)
     np.testing.assert_array_equal(st, st_ref[::-1])
-    # the batch API hands out pinned memory for big batches and plain arrays for small ones: same numbers
+    # the batch API: an ordinary array by default, pinned memory of the context on request (big batches): same numbers
     ctx.set_option("host_chunk", 1024)
     nt_big = 1001
     tb = np.ascontiguousarray(c["tSteps"])
     sig = batch.solve_batch(c["states"], W.indexes(), W.units(), c["iniPar"], c["thickness"], c["nx"], tb, ctx=ctx)
-    assert sig.shape == (B, nt_big)
+    assert sig.shape == (B, nt_big) and not isinstance(_root(sig), L.PinnedBuffer)
+    pin = batch.solve_batch(c["states"], W.indexes(), W.units(), c["iniPar"], c["thickness"], c["nx"], tb, ctx=ctx, pinned=True)
+    assert isinstance(_root(pin), L.PinnedBuffer)
+    np.testing.assert_array_equal(pin, sig)
     one = batch.solve_batch(c["states"][1000:1003], W.indexes(), W.units(), c["iniPar"][1000:1003], c["thickness"], c["nx"], tb,
-                            ctx=ctx)
+                            ctx=ctx, pinned=True)  # (a small batch: pinned=True changes nothing)
+    assert not isinstance(_root(one), L.PinnedBuffer)
     np.testing.assert_array_equal(sig[1000:1003], one)
-    del sig
+    # A pinned result outlives close(): the context is marked closed -- every further call raises -- and the native
+    # context (which owns the pinned memory) goes with the last buffer the caller holds (`sig = solve_batch(...);
+    # ctx.close(); sig.sum()` read freed memory)
     ctx.trim()
+    ctx.close()
+    with pytest.raises(RuntimeError, match="closed"):
+        ctx.set_option("host_chunk", 512)
+    with pytest.raises(RuntimeError, match="closed"):
+        batch.solve_batch(c["states"][:2], W.indexes(), W.units(), c["iniPar"][:2], c["thickness"], c["nx"], tb, ctx=ctx)
+    assert ctx._h is not None and ctx._pinned_live == 1
+    np.testing.assert_array_equal(pin, sig)  # still there, still the same numbers
+    assert float(pin.sum()) == float(sig.sum())
+    del pin
+    import gc
+    gc.collect()
+    assert ctx._h is None and ctx._pinned_live == 0  # the last buffer took the native context with it
+    # ... and a context nobody holds pinned memory of closes at once
+    ctx2 = L.Context(0)
+    L.pinned_f64(ctx2, 1 << 20)[:8] = 1.0  # (dropped at once: back to the context's free list)
+    ctx2.close()
+    assert ctx2._h is None
+
+
+def _root(a):
+    while getattr(a, "base", None) is not None:
+        a = a.base
+    return a
+
+
+def test_the_build_of_the_wave_kernel_chosen_per_launch():
+    """mtrpl_solve_batch_dev2: solves_per_simd = 1 / 2 picks the one- / two-solves-per-SIMD build for THAT launch, whatever
+    the context's two_per_simd_min_batch says; 0 is mtrpl_solve_batch_dev; the samples are the same bits on either build;
+    anything else is a bad argument.  What LikelihoodEngine.per_simd passes."""
+    import torch
+    from metrotrpl_amd import _lib as L, batch, workloads as W
+    dev = torch.device("cuda", 0)
+    ctx = L.Context(0)
+    c = W.config2(96)
+    t = np.ascontiguousarray(np.linspace(0, 300, 151))
+    d, ini = batch.build_batch(c["states"], W.indexes(), W.units(), c["iniPar"], c["thickness"], c["nx"], len(t))
+    B = d.shape[0]
+    dd = torch.from_numpy(d.view(np.uint8).reshape(-1)).to(dev)
+    di, dt = torch.from_numpy(ini).to(dev), torch.from_numpy(t).to(dev)
+    res = {}
+    for per in (0, 1, 2):
+        out = torch.full((B * len(t),), float("nan"), dtype=torch.float64, device=dev)
+        st = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        sa = torch.zeros(B * 8, dtype=torch.int32, device=dev)
+        ctx.check(L.lib().mtrpl_solve_batch_dev2(ctx.handle, B, dd.data_ptr(), di.data_ptr(), dt.data_ptr(), out.data_ptr(),
+                                                 st.data_ptr(), sa.data_ptr(), 128, 0, torch.cuda.current_stream().cuda_stream, per))
+        torch.cuda.synchronize()
+        assert bool((st == 0).all())
+        res[per] = (out.cpu().numpy(), sa.cpu().numpy().reshape(B, 8)[:, :7])
+    for per in (1, 2):
+        np.testing.assert_array_equal(res[per][0], res[0][0])
+        np.testing.assert_array_equal(res[per][1], res[0][1])
+    out = torch.zeros(B * len(t), dtype=torch.float64, device=dev)
+    st = torch.zeros(B, dtype=torch.int32, device=dev)
+    with pytest.raises(ValueError, match="solves_per_simd"):
+        ctx.check(L.lib().mtrpl_solve_batch_dev2(ctx.handle, B, dd.data_ptr(), di.data_ptr(), dt.data_ptr(), out.data_ptr(),
+                                                 st.data_ptr(), None, 128, 0, None, 3))
     ctx.close()
 
 
