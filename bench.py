@@ -266,7 +266,14 @@ def _api_leg(local, dev, B=8192, n_samples=8192):
                             meas=c["meas"], model=c["model"], ini_mode=c["ini_mode"], ctx=ctx)
     dt = time.perf_counter() - t0
     legs["python_batch_solve_batch"] = {"ms_per_call": dt * 1e3, "solves_per_sec": B / dt, "all_solves_ok": bool(np.all(np.isfinite(sig)))}
-    del sig
+    # ... and with the result left in the context's pinned memory (pinned=True: for results that are consumed and dropped)
+    t0 = time.perf_counter()
+    sigp = batch.solve_batch(c["states"], W.indexes(), W.units(), c["iniPar"], c["thickness"], c["nx"], t, hmax=c["hmax"],
+                             meas=c["meas"], model=c["model"], ini_mode=c["ini_mode"], ctx=ctx, pinned=True)
+    dt = time.perf_counter() - t0
+    legs["python_batch_solve_batch_pinned"] = {"ms_per_call": dt * 1e3, "solves_per_sec": B / dt,
+                                               "same_values": bool(np.array_equal(sigp, sig))}
+    del sig, sigp
     out["solve_batch"] = {"solves": B, "host_chunk": int(ctx.get_option("host_chunk")), "host_streams": int(ctx.get_option("host_streams")),
                           "solves_per_sec": legs["pinned_out"]["solves_per_sec"], **legs,
                           "note": "PCIe-inclusive: descriptors from host memory, 8 KB of samples per solve back into host "
