@@ -379,14 +379,21 @@ def pmc_file_fields(suffix, solves_per_launch):
 N_SIMD, CLOCK_HZ = 1024, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz max clock
 
 
-# Issue cost of the instruction classes with two waves per SIMD, cycles per wave-instruction per SIMD, measured on this
-# device by tools/mb/rcp_rate.hip (profiles/r0N_z_issue_cost.txt: v_add_f64 2.05 ns, v_fma_f64 2.52 ns, v_rcp_f64 7.9 ns
-# per wave-op per SIMD at 2.3 GHz; a wave ALONE on its SIMD issues an fp64 instruction only every 8 cycles)
-# (packed fp32 instructions are counted in the fp32 classes at 4 cycles although they cost about 6: the bound is
-# optimistic by about 4 %)
-ISSUE_COST_2WAVES = {"SQ_INSTS_VALU_ADD_F64": 4.7, "SQ_INSTS_VALU_FMA_F64": 5.8, "SQ_INSTS_VALU_MUL_F64": 5.8,
-                     "SQ_INSTS_VALU_TRANS_F64": 18.0, "SQ_INSTS_VALU_ADD_F32": 4.0, "SQ_INSTS_VALU_FMA_F32": 4.0,
-                     "SQ_INSTS_VALU_MUL_F32": 4.0, "SQ_INSTS_VALU_TRANS_F32": 8.0, "other": 4.0}
+# Issue cost of the instruction classes with two waves per SIMD, cycles (at 2.4 GHz) per wave-instruction per SIMD, measured
+# on this device by tools/mb/rcp_rate.hip (profiles/r06_z_issue_cost.txt, two waves per SIMD: v_add_f64 1.93 ns, v_fma_f64
+# 2.06 ns, v_rcp_f64 7.3 ns, v_fma_f32 1.20 ns, v_pk_fma_f32 1.95 ns per wave-op per SIMD).
+# ROUND 6 CORRECTION: rounds 3-5 priced v_fma_f64 at 5.8 and the fp32 classes at 4.0 -- their micro-benchmark ran eight
+# operations per trip of its loop and counted the loop's own compare-and-branch (about 20 cycles a trip) into them; with
+# 128 operations per trip an fp64 FMA costs 4.9 cycles and a wave ALONE on its SIMD issues one every 5.2 (not "every 8":
+# what a lone wave of the solve kernel loses is dependency and LDS / scalar-memory latency, not issue width).  The bound
+# is higher and the measured rate a smaller fraction of it than rounds 3-5 reported (config 2: 893 k solves/s and 76 %
+# where they said 829 k and 82-84 %).
+# (fp32 classes: scalar fp32 2.9 cycles, packed fp32 -- counted in the same classes -- 4.7; 3.5 is the blend at the kernel's
+# static ratio of one packed instruction in three.  "other" -- moves, selects, conversions, DPP, lane reads -- is not
+# classed by the counters: a 32-bit move costs 2.4, an fp64 conversion 4.5, a DPP move behind its wait state 6.5; 4.0 kept.)
+ISSUE_COST_2WAVES = {"SQ_INSTS_VALU_ADD_F64": 4.6, "SQ_INSTS_VALU_FMA_F64": 4.9, "SQ_INSTS_VALU_MUL_F64": 4.9,
+                     "SQ_INSTS_VALU_TRANS_F64": 17.0, "SQ_INSTS_VALU_ADD_F32": 3.5, "SQ_INSTS_VALU_FMA_F32": 3.5,
+                     "SQ_INSTS_VALU_MUL_F32": 3.5, "SQ_INSTS_VALU_TRANS_F32": 8.0, "other": 4.0}
 
 
 def _issue_cost_file(repo):
