@@ -229,3 +229,57 @@ def test_round5_bench_line_tells_the_whole_story():
     assert abs(r5["kernel_ms"] - c5["single_stream"]["kernel_ms"]) < 1e-9  # priced with the kernel's own duration ...
     assert r5["in_flight"]["kernel_ms"] > r5["kernel_ms"]                   # ... the four-in-flight bracket beside it
     assert r5["traffic"] is not None and "r05" in r5["traffic_source"]
+
+
+def test_leg_watchdog_emits_the_line_and_ends_the_job():
+    """bench.py at N > 1: a leg that outlives MTRPL_BENCH_LEG_TIMEOUT costs the contract line that leg's object, not the
+    line -- rank 0 emits what it has with {"pt": {"error": ...}} and exits 0; the other ranks exit 0 without a line."""
+    import json
+    import subprocess
+    import sys
+    import time
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "rank = int(sys.argv[1])\n"
+            "bench._leg_watchdog(rank, {'metric': 'trpl_forward_solves_per_sec', 'value': 1.0} if rank == 0 else None, 'pt')\n"
+            "time.sleep(30)\n"
+            "print('the leg came back')\n" % REPO)
+    env = dict(os.environ, MTRPL_BENCH_LEG_TIMEOUT="0.3")
+    for rank in (0, 1):
+        t0 = time.time()
+        r = subprocess.run([sys.executable, "-c", code, str(rank)], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-500:]
+        assert time.time() - t0 < 25 and "the leg came back" not in r.stdout
+        if rank == 0:
+            line = json.loads(r.stdout.strip().splitlines()[-1])
+            assert line["value"] == 1.0 and "did not finish" in line["pt"]["error"]
+        else:
+            assert r.stdout.strip() == ""
+
+
+def test_round6_bench_line_prices_its_roofline_with_the_corrected_issue_costs():
+    """The committed round-6 line: everything the round-5 line carried, the VALU-issue bound priced with the issue costs of the
+    corrected micro-benchmark (tools/mb/rcp_rate.hip: 128 operations per trip of its loop; rounds 3-5 counted the loop's branch
+    into eight -- profiles/r06_z_issue_cost.txt), and batch.solve_batch timed both ways (an ordinary array by default, the
+    context's pinned memory on request: same values)."""
+    import glob
+    import json
+    from metrotrpl_amd import pt_bench
+    path = sorted(glob.glob(os.path.join(REPO, "profiles", "r06_?_bench_config2.json")))[-1]
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    assert d["metric"] == "trpl_forward_solves_per_sec" and d["n_gpus"] == 1 and d["value"] >= 6.5e5
+    assert d["config"]["all_solves_ok"] is True and d["config"]["solves_per_simd"] == 2
+    t = d["roofline"]["valu_issue"]["throughput"]
+    assert "r06_z_issue_cost" in t["source"]
+    assert 8.5e5 < t["bound_solves_per_sec"] < 9.5e5 and 0.65 < t["frac_of_bound"] < 0.85
+    assert abs(t["frac_of_bound"] - d["value"] / t["bound_solves_per_sec"]) < 1e-9
+    assert pt_bench.ISSUE_COST_2WAVES["SQ_INSTS_VALU_FMA_F64"] == 4.9  # (5.8 until round 5)
+    # ... and the measurement it comes from: an fp64 FMA with two waves per SIMD, ns per wave-op per SIMD -> cycles at 2.4 GHz
+    txt = open(os.path.join(REPO, "profiles", "r06_z_issue_cost.txt")).read().split("== 2 wave(s) per SIMD")[1].split("==")[0]
+    ns = float([ln for ln in txt.splitlines() if ln.startswith("v_fma_f64")][0].split(",")[1].split()[0])
+    assert abs(ns * 2.4 - 4.9) < 0.15
+    sb = d["api"]["solve_batch"]
+    assert sb["python_batch_solve_batch"]["all_solves_ok"] is True and sb["python_batch_solve_batch_pinned"]["same_values"] is True
+    assert sb["pinned_out"]["solves_per_sec"] >= 4.5e5 and sb["python_batch_solve_batch"]["solves_per_sec"] >= 4.0e5
+    assert max(d["accuracy"]["max_rel_err_per_decade_0_to_8"]) < 1e-6
+    assert d["pt"]["64"]["ms_per_iteration"] <= 2.2 and d["pt"]["512"]["ms_per_iteration"] <= 6.3
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
