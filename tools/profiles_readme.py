@@ -95,7 +95,9 @@ for name, what in (("tail_decades.txt", "per-decade accuracy table (config 2 / c
                    ("api_streams.txt", "`mtrpl_solve_batch` host to host at B = 8192: sub-launch size x streams; and inside processes that own other streams, with 8 and 16 hardware queues"),
                    ("startup_trace.txt", "where the steps of a solve go along the time axis"), ("slow_solves.txt", "the slowest solves of the config-2 batch"),
                    ("variant_agreement.txt", "default kernel vs fp64-block kernel on 8192 draws"), ("solve_latency.txt", "latency of the drop-in `solve()`"),
-                   ("config5_sweep.txt", "config 5: fp32 / fp64 tolerance sweep on this build"), ("issue_cost.txt", "issue cost of the instruction classes"),
+                   ("config5_sweep.txt", "config 5: fp32 / fp64 tolerance sweep on this build"), ("issue_cost.txt", "issue cost of the instruction classes (`tools/mb/rcp_rate.hip`; from round 6 on with 128 operations per trip of its loop -- rounds 3-5 counted the loop's own branch into eight)"),
+                   ("xchg_cost.txt", "what an LDS exchange between the waves of a workgroup costs (`tools/mb/xchg_cost.hip`)"),
+                   ("soak.txt", "`tools/soak.py`: every solve kernel N times over the config-2 / config-5 batches, bytes and step counts repeat"),
                    ("step_phases.txt", "cycles per integrator step and phase (`-DMTRPL_STAMPS` diagnostic build): SPIKE at nx = 512, the one-wave kernel one and two per SIMD"),
                    ("pt64_timeline.txt", "64-chain PT from a `rocprofv3 --kernel-trace`: per hardware queue (= chain group) the solve / likelihood kernel times and the gap from one solve to the next; per stretch between two exchanges when each group starts and ends"),
                    ("pt512_timeline.txt", "the same for the 512-chain ensemble"),
