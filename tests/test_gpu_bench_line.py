@@ -74,6 +74,7 @@ def test_two_rank_bench_line_rehearsed_on_one_gpu():
     assert abs(d["value"] - 2 * 1024 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]  # whole-job rate: both ranks' solves
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0     # at N > 1 too
     assert "roofline" in d and "api" in d and d["accuracy"]["all_ok"] is True
+    assert d["multi_gpu"]["first_run_on_hardware"] is True  # (the N > 1 line says that no multi-GPU hardware had run it)
     p = d["pt"]["512"]
     assert p["n_gpus"] == 2 and p["scaling"] == "strong" and p["chains"] == 512 and p["ms_per_iteration"] > 0
     assert 0 < p["collectives_per_iteration"] <= 0.2 and len(p["max_integrator_steps_per_rank"]) == 2
